@@ -1,0 +1,198 @@
+"""Host-side mirror of the reference's driver plugin surface, on top of the C-ABI.
+
+What is mirrored (reference paths):
+  * roster entries {"driver": "file://a/b.py" | "a.b", "name": ...} -> module path -> ``module.Driver()``
+    with a null-driver fallback on import failure -- ft_grandprix/custom.py:1096-1109, template/cars/cars.json
+  * arity sniffing: ``process_lidar(ranges)`` or ``process_lidar(ranges, snapshot)`` -- custom.py:103,1398-1399
+  * per step and per car: ranges (1-D float64, index 0 = rear, CCW), snapshot (VehicleStateSnapshot),
+    ``speed, steering_angle = driver.process_lidar(...)``; an exception prints a message and leaves that
+    car's previous controls in place -- custom.py:1395-1411,1421-1423
+  * finished cars are handed the null driver -- custom.py:1367-1371,1446
+  * ``reset()`` = Mujoco.reload(): drivers re-instantiated, race state cleared, cars re-spawned -- custom.py:1089-1128
+The physics / LiDAR / lap logic themselves run on the GPU behind ``capi.Env``.
+"""
+from __future__ import annotations
+
+import importlib
+import inspect
+import json
+import math
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import capi
+from .track import Track
+from .vehicle import VehicleStateSnapshot
+
+
+class LobotomyDriver:
+    """Null driver: (0, 0).  Fallback on import failure and for finished cars (lobotomy.py:1-3)."""
+
+    def process_lidar(self, ranges):
+        return 0, 0
+
+
+def ordinal(n) -> str:
+    """1 -> '1st' ... as custom.py:47-55 (including its 11th/12th/13th and '0th' rules)."""
+    n = str(n)
+    if n == "0" or (len(n) > 1 and n[-2] == "1"):
+        e = "th"
+    elif n[-1] == "1":
+        e = "st"
+    elif n[-1] == "2":
+        e = "nd"
+    elif n[-1] == "3":
+        e = "rd"
+    else:
+        e = "th"
+    return n + e
+
+
+def lap_completion(completion: int, good_start: bool) -> int:
+    """custom.py:132-140: negative while running a lap that was entered backwards."""
+    return completion if good_start else -(100 - completion)
+
+
+def absolute_completion(laps: int, completion: int, good_start: bool) -> int:
+    """custom.py:142-143."""
+    return laps * 100 + lap_completion(completion, good_start)
+
+
+def quaternion_to_euler(w, x, y, z):
+    """[yaw, pitch, roll] with the asin clamp of custom.py:62-76."""
+    roll = math.atan2(2.0 * (w * x + y * z), 1.0 - 2.0 * (x * x + y * y))
+    t2 = 2.0 * (w * y - z * x)
+    t2 = 1.0 if t2 > 1.0 else t2
+    t2 = -1.0 if t2 < -1.0 else t2
+    pitch = math.asin(t2)
+    yaw = math.atan2(2.0 * (w * z + x * y), 1.0 - 2.0 * (y * y + z * z))
+    return [yaw, pitch, roll]
+
+
+def resolve_driver_path(spec: str) -> Optional[str]:
+    """Roster 'driver' string -> importable module path (custom.py:1097-1104)."""
+    if spec.startswith("file://"):
+        return spec[7:-3].replace("/", ".")
+    if "//" not in spec:
+        return spec
+    print("Unsupported schema: supported (file://)")
+    return None
+
+
+def load_driver(path: Optional[str]):
+    try:
+        return importlib.import_module(path).Driver()
+    except Exception:
+        return LobotomyDriver()
+
+
+class VehicleState:
+    """Per-car race state + driver handle (the fields of custom.py:91-126 that drivers and dashboards read)."""
+
+    def __init__(self, id: int, offset: int, driver, label: str, driver_path: Optional[str]):
+        self.id, self.offset, self.driver, self.label, self.driver_path = id, offset, driver, label, driver_path
+        self.v2 = len(inspect.signature(self.driver.process_lidar).parameters) >= 2
+        self.completion, self.laps, self.start, self.delta = 0, 0, 0, 0
+        self.good_start, self.finished, self.off_track = True, False, False
+        self.speed, self.steering_angle = 0.0, 0.0
+        self.times: List[float] = []
+
+    def lap_completion(self):
+        return lap_completion(self.completion, self.good_start)
+
+    def absolute_completion(self):
+        return absolute_completion(self.laps, self.completion, self.good_start)
+
+    def reload_code(self):
+        self.driver = load_driver(self.driver_path)
+        self.v2 = len(inspect.signature(self.driver.process_lidar).parameters) >= 2
+
+
+class Simulator:
+    """Batched worlds with Python drivers: one ``Driver`` instance per car, called in car order every step."""
+
+    def __init__(self, track: Track, cars: Sequence[dict], n_envs: int = 1, n_rays: int = 90, lap_target: int = 10,
+                 lib: Optional[capi.CLib] = None, spawn_mode: int = 0, seed: int = 1234, device_id: int = 0):
+        self.lib = lib if lib is not None else capi.load()
+        self.cars = list(cars)
+        self.env = capi.Env(self.lib, track, n_envs=n_envs, cars_per_env=len(self.cars), n_rays=n_rays,
+                            lap_target=lap_target, spawn_mode=spawn_mode, seed=seed, device_id=device_id)
+        self.n_envs, self.cars_per_env, self.n_rays = n_envs, len(self.cars), n_rays
+        self.timestep = self.env.dt
+        self.steps = 0
+        self.vehicle_states: List[VehicleState] = []
+        self.winners = {}
+        self.reset()
+
+    @staticmethod
+    def load_roster(path: str) -> list:
+        with open(path) as f:
+            return json.load(f)
+
+    def close(self):
+        self.env.close()
+
+    # reload(): custom.py:1089-1128
+    def reset(self):
+        self.env.reset()
+        states = []
+        for e in range(self.n_envs):
+            for i, car in enumerate(self.cars):
+                path = resolve_driver_path(car["driver"])
+                states.append(VehicleState(id=e * self.cars_per_env + i, offset=(i + 5) * 2, driver=load_driver(path),
+                                           label=car.get("name", f"car #{i}"), driver_path=path))
+        self.vehicle_states = states
+        self.steps = 0
+        self.winners = {}
+        self._sync_race_state()
+
+    def _sync_race_state(self):
+        prog = self.env.progress()
+        counts, times = self.env.lap_times()
+        for vs in self.vehicle_states:
+            p = prog[vs.id]
+            vs.laps, vs.completion, vs.start, vs.delta = int(p[0]), int(p[1]), int(p[6]), int(p[8])
+            vs.good_start, vs.off_track = bool(p[7]), bool(p[5])
+            vs.times = [float(t) for t in times[vs.id, : min(int(counts[vs.id]), capi.MAX_LAP_TIMES)]]
+            if p[4] and not vs.finished:           # custom.py:1367-1371 + 1446
+                if vs.id not in self.winners:
+                    self.winners[vs.id] = len(self.winners) + 1
+                vs.finished = True
+                vs.driver = LobotomyDriver()
+                vs.v2 = False
+
+    def snapshots(self) -> List[VehicleStateSnapshot]:
+        snap = self.env.snapshot()
+        return [VehicleStateSnapshot(laps=int(s[0]), velocity=s[1:4].copy(), yaw=float(s[4]), pitch=float(s[5]),
+                                     roll=float(s[6]), lap_completion=int(s[7]), absolute_completion=int(s[8]),
+                                     time=float(s[9])) for s in snap]
+
+    def step(self):
+        """One iteration of the reference's physics loop body (custom.py:1337-1426)."""
+        ranges = self.env.lidar().astype(np.float64)
+        snaps = self.snapshots() if any(vs.v2 for vs in self.vehicle_states) else None
+        ctrl = np.zeros((self.env.n_cars, 2))
+        mask = np.ones(self.env.n_cars, dtype=np.uint8)
+        for vs in self.vehicle_states:
+            args = [ranges[vs.id], snaps[vs.id]] if vs.v2 else [ranges[vs.id]]
+            try:
+                speed, steering_angle = vs.driver.process_lidar(*args)
+            except Exception as e:
+                print(f"Error in vehicle `{vs.label}`: `{e}`")
+                mask[vs.id] = 0
+                continue
+            vs.speed, vs.steering_angle = speed, steering_angle
+            ctrl[vs.id] = (speed, steering_angle)
+        self.env.set_ctrl(ctrl, mask)
+        self.env.step(1)
+        self.steps += 1
+        self._sync_race_state()
+
+    def drive(self, n_steps: int):
+        for _ in range(n_steps):
+            self.step()
+
+    def ranking(self) -> List[int]:
+        """Car ids by absolute completion, best first (the dashboard order of custom.py:335)."""
+        return [vs.id for vs in sorted(self.vehicle_states, key=lambda v: -v.absolute_completion())]

@@ -1,0 +1,215 @@
+/*
+ * ftgp.h -- C-ABI of the MI355X-native ft_grandprix hot path
+ *           (vehicle integrate + LiDAR sweep + lap progress, batched over envs).
+ *
+ * This is the drop-in boundary.  The reference has no FFI:
+ * its hot loop talks to MuJoCo's Python bindings.  Each entry point below names
+ * the reference call sites it replaces (paths relative to the reference repo).
+ *
+ * Conventions: extern "C", opaque handle, int status (0 = ok, negative = error,
+ * text via ftgp_last_error()), plain pointers and sizes only.  The caller owns
+ * all host buffers; device buffers are owned by the handle.  A handle is not
+ * thread-safe; independent handles are.
+ *
+ * Layout conventions for per-car arrays: index = (env * cars_per_env + car).
+ */
+#ifndef FTGP_H
+#define FTGP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FTGP_ABI_VERSION 1
+
+/* status codes */
+#define FTGP_OK              0
+#define FTGP_ERR_ARG        -1   /* bad argument / config */
+#define FTGP_ERR_NO_DEVICE  -2   /* no HIP device (the product path has no CPU fallback) */
+#define FTGP_ERR_HIP        -3   /* HIP runtime error */
+#define FTGP_ERR_STATE      -4   /* call not valid in the handle's current state */
+#define FTGP_ERR_COMM       -5   /* RCCL error */
+
+/* device-side policies for ftgp_rollout; FTGP_POLICY_HOST = ctrl comes from ftgp_set_ctrl */
+#define FTGP_POLICY_HOST      0
+#define FTGP_POLICY_LOBOTOMY  1  /* ft_grandprix/lobotomy.py:2-3 : (0, 0)                    */
+#define FTGP_POLICY_NIDC      2  /* ft_grandprix/nidc.py:116-131 : disparity extender         */
+#define FTGP_POLICY_FAST      3  /* ft_grandprix/fast.py:118-139 : same + straight-line boost */
+#define FTGP_POLICY_RANDOM    4  /* counter-based RNG keyed (seed, car, step): speed~U(0,3), steer~U(-1,1) */
+
+#define FTGP_PATH_POINTS   100   /* ft_grandprix/curve.py:8 */
+#define FTGP_MAX_LAP_TIMES  16   /* lap times kept per car (oldest kept; lap_target default is 10, custom.py:961) */
+
+/* number of doubles / ints per car in the packed read-back rows */
+#define FTGP_SNAPSHOT_DOUBLES 10 /* laps, vel[3], yaw, pitch, roll, lap_completion, absolute_completion, time */
+#define FTGP_POSE_DOUBLES     13 /* qpos[7] = x y z qw qx qy qz ; qvel[6] = vx vy vz wx wy wz */
+#define FTGP_PROGRESS_INTS     9 /* laps, completion, lap_completion, absolute_completion, finished, off_track, start, good_start, delta */
+#define FTGP_METRIC_DOUBLES    8 /* steps, n_cars, sum_laps, sum_abs_completion, n_finished, n_off_track, min_lap_time, max_lap_time */
+
+/*
+ * Track geometry (built by ft_grandprix_amd/track.py from <track>.png + <track>-path.svg).
+ *   wall bitmap : ft_grandprix/chunk.py:39-43 threshold (wall iff pure white)
+ *   wall frame  : template/mushr.em.xml:17-20,55,92 (pixel (px,py) covers
+ *                 x in [origin_x + px*px_size_x, +px_size_x), y in (origin_y - (py+1)*px_size_y, origin_y - py*px_size_y])
+ *   path        : ft_grandprix/curve.py:6-18 + ft_grandprix/custom.py:1184-1186 (100 x (x, y), float64)
+ */
+typedef struct FtgpTrack {
+    int32_t width, height;          /* pixels */
+    int32_t words_per_row;          /* uint32 words per bitmap row = ceil(width/32) */
+    int32_t reserved0;
+    const uint32_t *bits;           /* [height][words_per_row]; bit (x & 31) of word (x >> 5), 1 = wall */
+    double px_size_x, px_size_y;    /* world units per pixel */
+    double origin_x, origin_y;      /* world position of the top-left corner of pixel (0, 0) */
+    const double *path;             /* [FTGP_PATH_POINTS][2] world coordinates */
+} FtgpTrack;
+
+/*
+ * Vehicle parameters: the reduced planar model of the MuSHR car of
+ * template/mushr.em.xml:61-89,95-198 (see DESIGN.md "K1").  ftgp_default_vehicle() fills
+ * the values lifted from that file.
+ */
+typedef struct FtgpVehicle {
+    double mass, izz;               /* total mass, yaw inertia about the CoM */
+    double wheel_x[4], wheel_y[4];  /* fl, fr, bl, br contact points, body frame (mushr.em.xml:124,137,150,162) */
+    double wheel_radius;            /* 0.03 (mushr.em.xml:24,69) */
+    double wheel_inertia;           /* spin inertia incl. armature 0.01 (mushr.em.xml:81) */
+    double wheel_damping;           /* 0.01 (mushr.em.xml:81) */
+    double throttle_kv, throttle_gear, throttle_force_limit; /* 100, 0.04, 500 (mushr.em.xml:180) */
+    double steer_kp, steer_damping, steer_inertia, steer_limit; /* 20, 3*0.1, ~8e-4, 1 rad (mushr.em.xml:78,179) */
+    double friction, gravity;       /* 0.5 = max(wheel 0.3, plane 0.5) (mushr.em.xml:69,94); 9.81 */
+    double tire_damping;            /* slip-velocity coupling per wheel, N s/m (from solref 0.02/solimp 0.95, mushr.em.xml:69) */
+    double contact_x[3];            /* body-frame x of the 3 wall/car contact circles */
+    double contact_radius;
+    double contact_stiffness, contact_damping; /* penalty spring/damper against walls and other cars */
+    double lidar_x, lidar_y;        /* LiDAR centre, body frame: (-0.0525, 0) (mushr.em.xml:101) */
+    double lidar_ring_radius;       /* 0.03: ray j starts at centre - 0.03*dir_j (mushr.em.xml:103,115) */
+    double body_z;                  /* constant ride height reported in qpos[2] */
+    double box_xmin, box_xmax, box_ymin, box_ymax; /* chassis bbox, body frame, seen by other cars' rays */
+} FtgpVehicle;
+
+typedef struct FtgpConfig {
+    int32_t abi_version;            /* FTGP_ABI_VERSION */
+    int32_t n_envs;
+    int32_t cars_per_env;           /* 1..8; cars of one env share a world (template/cars/cars.json) */
+    int32_t n_rays;                 /* rangefinders per car (custom.py:1158 uses 90; BASELINE uses 1080) */
+    int32_t lap_target;             /* custom.py:961, used custom.py:1367 */
+    int32_t device_id;              /* HIP device ordinal */
+    int32_t spawn_mode;             /* 0 = reference: car i at path[(i+5)*2] (custom.py:1112,1232-1245);
+                                       1 = benchmark spread: env e, car i at path[(10 + 7*e + 2*i) % 98] with seeded yaw jitter */
+    int32_t reserved0;
+    uint64_t seed;                  /* spawn jitter and FTGP_POLICY_RANDOM */
+    double dt;                      /* 0.004 (mushr.em.xml:30) */
+    FtgpTrack track;
+    FtgpVehicle vehicle;
+} FtgpConfig;
+
+typedef struct FtgpEnv FtgpEnv;
+
+/* Fill *v with the MuSHR constants of template/mushr.em.xml. */
+void ftgp_default_vehicle(FtgpVehicle *v);
+
+/* Text of the last error raised on the calling thread. */
+const char *ftgp_last_error(void);
+
+/* Number of visible HIP devices (<= 0 when there is none). */
+int ftgp_device_count(void);
+
+/*
+ * Build the world.  Replaces Mujoco.stage(): chunk() + produce_mjcf() + MjModel.from_xml_path +
+ * MjData + path load (ft_grandprix/custom.py:1133-1194; drive.py:21-46).  Uploads the track,
+ * builds the ray-march acceleration grid, allocates per-car state and calls ftgp_reset(NULL).
+ */
+int ftgp_create(const FtgpConfig *cfg, FtgpEnv **out);
+int ftgp_destroy(FtgpEnv *env);
+
+/*
+ * Reset.  Replaces Mujoco.reload() = mj_resetData + VehicleState rebuild + position_vehicles
+ * (custom.py:1089-1128,1232-1245,81-87).  mask: NULL = all envs, else uint8[n_envs], non-zero = reset.
+ * After reset: qvel = 0, ctrl = 0, LiDAR ranges = 0 (custom.py:1092), steps of the
+ * env = 0, race state cleared, progress evaluated once at the spawn pose.
+ */
+int ftgp_reset(FtgpEnv *env, const uint8_t *mask);
+
+/*
+ * Controls.  Replaces data.ctrl[forward] = speed; data.ctrl[turn] = steering_angle
+ * (custom.py:1421-1423; drive.py:82-83).  ctrl: double[n_envs*cars_per_env][2] = (speed, steering_angle).
+ * car_mask (may be NULL): uint8 per car, 0 = leave that car's ctrl unchanged -- the reference's
+ * behaviour when a driver raises (custom.py:1409-1411).
+ */
+int ftgp_set_ctrl(FtgpEnv *env, const double *ctrl, const uint8_t *car_mask);
+
+/*
+ * n_steps iterations of: sensors at the current pose -> integrate one dt -> steps += 1 ->
+ * lap progress at the new pose.  Replaces mujoco.mj_step + steps += 1 (custom.py:1425-1426;
+ * drive.py:89) followed by the progress block of the next loop iteration (custom.py:1340-1372).
+ * Controls stay at their last ftgp_set_ctrl value.
+ */
+int ftgp_step(FtgpEnv *env, int n_steps);
+
+/*
+ * Same loop with the driver evaluated on the device between progress and integrate:
+ * per step: policy(ranges of the previous step) -> ctrl -> sensors -> integrate -> progress.
+ * This is the throughput path; one launch covers all n_steps.
+ */
+int ftgp_rollout(FtgpEnv *env, int policy, int n_steps);
+
+/* Read-backs (host buffers).  All are synchronous with respect to earlier calls on the handle. */
+
+/* float[n_cars][n_rays]; replaces data.sensordata[vehicle_state.sensors] (custom.py:1395; drive.py:81).
+ * Index 0 = rear, counter-clockwise; world units; -1 = no hit; all 0 right after reset. */
+int ftgp_get_lidar(FtgpEnv *env, float *out);
+
+/* double[n_cars][FTGP_SNAPSHOT_DOUBLES]; replaces VehicleState.snapshot (custom.py:149-160,62-76;
+ * vehicle.py:3-12) incl. the reference's time = steps / timestep (custom.py:1397). */
+int ftgp_get_snapshot(FtgpEnv *env, double *out);
+
+/* double[n_cars][FTGP_POSE_DOUBLES]; replaces joint.qpos / joint.qvel reads (custom.py:1340; 149-152). */
+int ftgp_get_pose(FtgpEnv *env, double *out);
+
+/* int32[n_cars][FTGP_PROGRESS_INTS]; replaces the VehicleState race fields (custom.py:91-143,1340-1372). */
+int ftgp_get_progress(FtgpEnv *env, int32_t *out);
+
+/* counts: int32[n_cars]; times: double[n_cars][FTGP_MAX_LAP_TIMES]; replaces VehicleState.times (custom.py:124,1351-1363). */
+int ftgp_get_lap_times(FtgpEnv *env, int32_t *counts, double *times);
+
+/* double[n_cars][2] current controls. */
+int ftgp_get_ctrl(FtgpEnv *env, double *out);
+
+/* int64[n_envs] physics steps since each env's last reset (self.steps, custom.py:1124,1426). */
+int ftgp_get_steps(FtgpEnv *env, int64_t *out);
+
+/* Overwrite poses (testing / curriculum): double[n_cars][FTGP_POSE_DOUBLES]; only x, y, yaw (from qw, qz), vx, vy, wz are used. */
+int ftgp_set_pose(FtgpEnv *env, const double *pose);
+
+/* Re-evaluate the lap-progress block (custom.py:1340-1372) at the current poses and step counts, without integrating.
+ * ftgp_reset ends with this; use it after ftgp_set_pose. */
+int ftgp_eval_progress(FtgpEnv *env);
+
+/* Local metrics record (double[FTGP_METRIC_DOUBLES]) reduced on the device. */
+int ftgp_metrics_local(FtgpEnv *env, double *out);
+
+/*
+ * Multi-GPU: one handle per rank, envs sharded, no data-path collective.
+ * The only exchange is the end-of-step metrics all-gather over RCCL.
+ *   ftgp_comm_unique_id : rank 0 creates the 128-byte RCCL id; the host ships it to the other ranks.
+ *   ftgp_comm_init      : ncclCommInitRank on the handle's device.
+ *   ftgp_metrics_allgather : out = double[world_size][FTGP_METRIC_DOUBLES]; runs on a side stream.
+ * Nothing in the reference to mirror (it has no collective call sites).
+ */
+int ftgp_comm_unique_id(uint8_t id_out[128]);
+int ftgp_comm_init(FtgpEnv *env, const uint8_t id[128], int rank, int world_size);
+int ftgp_metrics_allgather(FtgpEnv *env, double *out);
+
+/* Timing of the most recent ftgp_step / ftgp_rollout launch sequence, measured with HIP events on the handle's stream (ms). */
+int ftgp_last_kernel_ms(FtgpEnv *env, float *ms);
+
+/* Name of the kernel that ftgp_rollout/ftgp_step launches for the current configuration (for rocprof matching). */
+const char *ftgp_kernel_name(FtgpEnv *env);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FTGP_H */

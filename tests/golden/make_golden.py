@@ -1,0 +1,265 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by RUNNING the reference's own Python.
+
+Run once in the build container (needs /root/reference; never runs on the GPU box):
+    python tests/golden/make_golden.py [/root/reference]
+
+Fixtures (data only -- inputs and the reference's outputs):
+  g1_drivers.npz   nidc / fast / lobotomy / drivers.template process_lidar on seeded scans, R in {36, 90, 1080}
+  g2_fakelidar.npz ft_grandprix.raycast.fakelidar on each track's EDT from on-track origins, R in {36, 1080}
+  g3_chunk.json    ft_grandprix.chunk.chunk() metadata.json for the 4 tracks + SHA-256 of the chunk pixels
+  g4_math.npz      custom.quaternion_to_euler / euler_to_quaternion / quaternion_to_angle, VehicleState
+                   lap_completion / absolute_completion truth table, ordinal()
+  g5_progress.npz  the lap-progress block custom.py:1340-1372 executed verbatim (sliced from the source text
+                   and exec'd against stub objects) on hand-built position traces
+
+custom.py imports mujoco / dearpygui / empy / svg.path, which are not installed; they are replaced by
+MagicMock entries in sys.modules for the import only -- none of the functions
+exercised here touches them.
+"""
+import hashlib
+import json
+import os
+import sys
+import tempfile
+import textwrap
+import types
+from unittest import mock
+
+import numpy as np
+
+REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REF)
+sys.path.insert(0, os.path.join(HERE, "..", ".."))
+
+from ft_grandprix import nidc, fast, lobotomy, raycast, chunk as ref_chunk  # noqa: E402
+from drivers import template as ref_template  # noqa: E402
+
+
+# ----------------------------------------------------------------------------- G1
+def scans(rng, R, n):
+    """Seeded scans, binary32-representable (the device LiDAR is f32), returned as float64 arrays."""
+    out = []
+    ang = np.linspace(0, 2 * np.pi, R, endpoint=False)
+    for k in range(n):
+        kind = k % 8
+        if kind == 0:
+            r = rng.uniform(0.2, 8.0, R)
+        elif kind == 1:   # smooth corridor-like profile with a few step disparities
+            r = 1.5 + 1.0 * np.cos(ang * rng.integers(1, 4) + rng.uniform(0, 6.28)) + 0.3 * rng.uniform(0, 1, R)
+            for _ in range(rng.integers(1, 6)):
+                a, b = sorted(rng.integers(0, R, 2))
+                r[a:b] += rng.uniform(0.7, 4.0)
+        elif kind == 2:   # no-hit markers
+            r = rng.uniform(0.2, 8.0, R)
+            r[rng.uniform(0, 1, R) < 0.05] = -1.0
+        elif kind == 3:   # zeros (first step after reset) and near-zeros
+            r = rng.uniform(0.2, 8.0, R) if k % 16 == 3 else np.zeros(R)
+            if k % 16 == 3:
+                r[rng.integers(0, R, max(1, R // 20))] = 0.0
+        elif kind == 4:   # ranges[0] straddling fast's 0.5 threshold, nearly straight-ahead maximum
+            r = 2.0 + 0.5 * np.cos(ang - np.pi) + 0.01 * rng.uniform(0, 1, R)
+            r[R // 2 + rng.integers(-2, 3)] = 9.0
+            r[0] = rng.choice([0.49, 0.5, 0.51, 0.2, 3.0])
+        elif kind == 5:   # disparities close to the array ends (cover loops hit the bounds)
+            r = rng.uniform(2.0, 2.5, R)
+            e = R // 8
+            r[e + rng.integers(0, 3)] += 3.0
+            r[R - e - 1 - rng.integers(0, 3)] += 3.0
+            r[e + 5: e + 8] = 0.25
+        elif kind == 6:   # differences right at the 0.6 threshold (binary32 neighbours of 0.6)
+            r = np.full(R, 1.0)
+            idx = rng.integers(R // 8 + 2, R - R // 8 - 2, 6)
+            r[idx] = 1.0 + np.array([0.6, 0.6000001, 0.5999999, 0.61, 0.59, 2.0])
+        else:             # plateaus: ties for the argmax
+            r = np.round(rng.uniform(0.2, 4.0, R), 1)
+        out.append(np.float32(r).astype(np.float64))
+    return np.stack(out)
+
+
+def gen_g1():
+    rng = np.random.default_rng(20240601)
+    data = {}
+    for R in (36, 90, 1080):
+        S = scans(rng, R, 64)
+        res = {k: np.zeros((len(S), 2)) for k in ("nidc", "fast", "lobotomy", "template")}
+        d_fast = fast.Driver()  # one instance, called in sequence (keeps last_steering_angle)
+        for i, r in enumerate(S):
+            with np.errstate(all="ignore"):
+                res["nidc"][i] = nidc.Driver().process_lidar(r.copy())
+                res["fast"][i] = d_fast.process_lidar(r.copy())
+            res["lobotomy"][i] = lobotomy.Driver().process_lidar(r.copy())
+            res["template"][i] = ref_template.Driver().process_lidar(r.copy(), None)
+        data[f"scans_{R}"] = S.astype(np.float32)
+        for k, v in res.items():
+            data[f"{k}_{R}"] = v
+    np.savez_compressed(os.path.join(HERE, "g1_drivers.npz"), **data)
+    print("g1: ok", {k: v.shape for k, v in data.items() if k.startswith("scans")})
+
+
+# ----------------------------------------------------------------------------- G2
+def gen_g2():
+    from scipy.ndimage import distance_transform_edt
+    from ft_grandprix_amd.track import load_track_from_template
+    rng = np.random.default_rng(7)
+    data = {}
+    for name in ("track", "circle", "small-circle", "inkscape"):
+        t = load_track_from_template(os.path.join(REF, "template"), name)
+        dt = distance_transform_edt(~t.wall_mask())
+        # on-track origins: the centre-line samples mapped back to pixels, plus jitter
+        px = t.path[:, 0] / 40.0 * t.width
+        py = -t.path[:, 1] / 40.0 * t.height
+        idx = rng.choice(100, 32, replace=False)
+        ox = px[idx] + rng.uniform(-4, 4, 32)
+        oy = py[idx] + rng.uniform(-4, 4, 32)
+        for R in (36, 1080):
+            yaw = rng.uniform(-np.pi, np.pi, 32)
+            scan = np.zeros((32, R)); pts = np.zeros((32, R, 2)); angs = np.zeros((32, R))
+            for k in range(32):
+                a = np.linspace(yaw[k] + np.pi, yaw[k] - np.pi, R, endpoint=False)  # custom.py:1387
+                angs[k] = a
+                scan[k], pts[k] = raycast.fakelidar(ox[k], oy[k], dt, R, np.cos(a), np.sin(a))
+            data[f"{name}_{R}_angles"] = angs
+            data[f"{name}_{R}_scan"] = scan
+            data[f"{name}_{R}_points"] = pts
+        data[f"{name}_origins"] = np.stack([ox, oy], axis=1)
+    np.savez_compressed(os.path.join(HERE, "g2_fakelidar.npz"), **data)
+    print("g2: ok")
+
+
+# ----------------------------------------------------------------------------- G3
+def gen_g3():
+    from PIL import Image
+    out = {}
+    cwd = os.getcwd()
+    for name in ("track", "circle", "small-circle", "inkscape"):
+        with tempfile.TemporaryDirectory() as td:
+            os.chdir(td)
+            try:
+                ref_chunk.chunk(os.path.join(REF, "template", f"{name}.png"), verbose=False, force=True, scale=2.0)
+                with open("rendered/chunks/metadata.json") as f:
+                    meta = json.load(f)
+                h = hashlib.sha256()
+                white = 0
+                for i, j in meta["chunks"]:
+                    a = np.asarray(Image.open(f"rendered/chunks/{i:03}x{j:03}.png").convert("RGB"))
+                    h.update(a.tobytes())
+                    white += int((a.astype(int).sum(2) == 765).sum())
+                out[name] = {"metadata": meta, "chunk_pixels_sha256": h.hexdigest(), "white_pixels": white}
+            finally:
+                os.chdir(cwd)
+    with open(os.path.join(HERE, "g3_chunk.json"), "w") as f:
+        json.dump(out, f)
+    print("g3: ok", {k: (len(v["metadata"]["chunks"]), v["white_pixels"]) for k, v in out.items()})
+
+
+# ----------------------------------------------------------------------------- G4 / G5 need custom.py
+def import_custom():
+    for m in ("mujoco", "mujoco.viewer", "dearpygui", "dearpygui.dearpygui", "em", "svg", "svg.path",
+              "OpenGL", "OpenGL.GL", "glfw"):
+        sys.modules.setdefault(m, mock.MagicMock())
+    import importlib
+    return importlib.import_module("ft_grandprix.custom")
+
+
+def gen_g4(custom):
+    rng = np.random.default_rng(11)
+    q = rng.normal(size=(256, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    # planar (yaw-only) quaternions and gimbal-lock clamps
+    yaw = rng.uniform(-np.pi, np.pi, 64)
+    q[:64] = np.stack([np.cos(yaw / 2), np.zeros(64), np.zeros(64), np.sin(yaw / 2)], axis=1)
+    q[64] = [np.sqrt(0.5), 0, np.sqrt(0.5), 0]; q[65] = [np.sqrt(0.5), 0, -np.sqrt(0.5), 0]
+    eul = np.array([custom.quaternion_to_euler(*row) for row in q])
+    ang = np.array([custom.quaternion_to_angle(*row) for row in q])
+    e_in = rng.uniform(-np.pi, np.pi, size=(256, 3)); e_in[:64, 1:] = 0.0
+    quat = np.array([custom.euler_to_quaternion(list(row)) for row in e_in], dtype=np.float64)
+    # VehicleState accessors: truth table over (completion, laps, good_start)
+    rows = []
+    vs = custom.VehicleState.__new__(custom.VehicleState)
+    for laps in (-2, -1, 0, 1, 9):
+        for completion in (0, 1, 37, 50, 99):
+            for good in (True, False):
+                vs.laps, vs.completion, vs.good_start = laps, completion, good
+                rows.append([laps, completion, int(good), vs.lap_completion(), vs.absolute_completion()])
+    ords = [custom.ordinal(n) for n in range(0, 125)]
+    np.savez_compressed(os.path.join(HERE, "g4_math.npz"), quats=q, eulers=eul, angles=ang,
+                        euler_in=e_in, quat_out=quat, vehicle_state=np.array(rows, dtype=np.int64),
+                        ordinals=np.array(ords))
+    print("g4: ok")
+
+
+def progress_block_source():
+    """The text of custom.py's per-car progress block (custom.py:1340-1372), located by its first/last statements."""
+    lines = open(os.path.join(REF, "ft_grandprix", "custom.py")).read().split("\n")
+    a = next(i for i, l in enumerate(lines) if "xpos = vehicle_state.joint.qpos[0:2]" in l)
+    b = next(i for i, l in enumerate(lines) if "vehicle_state.completion = completion" in l and i > a)
+    return textwrap.dedent("\n".join(lines[a:b + 1]))
+
+
+def gen_g5():
+    src = progress_block_source()
+    code = compile(src, "custom.py:progress-block", "exec")
+    rng = np.random.default_rng(5)
+    from ft_grandprix_amd.track import load_track_from_template
+    t = load_track_from_template(os.path.join(REF, "template"), "track")
+    path = t.path
+    dt = 0.004
+
+    def run(xy, offset, lap_target):
+        vs = types.SimpleNamespace(id=0, offset=offset, completion=0, good_start=True, finished=False, delta=0,
+                                   distance_from_track=0.0, start=0, laps=0, times=[], off_track=False,
+                                   joint=types.SimpleNamespace(qpos=np.zeros(7)))
+        shadowed = []
+        slf = types.SimpleNamespace(path=path, steps=0, winners={}, shadow=lambda i: shadowed.append(i),
+                                    option=lambda k: {"lap_target": lap_target}[k],
+                                    model=types.SimpleNamespace(opt=types.SimpleNamespace(timestep=dt)))
+        out = np.zeros((len(xy), 7), dtype=np.int64); d2 = np.zeros(len(xy)); tt = []
+        for s, p in enumerate(xy):
+            slf.steps = s
+            vs.joint.qpos[0:2] = p
+            exec(code, {"np": np, "abs": abs, "len": len}, {"self": slf, "vehicle_state": vs})
+            out[s] = [vs.laps, vs.completion, int(vs.good_start), len(vs.times), int(vs.finished), vs.delta, int(vs.off_track)]
+            d2[s] = vs.distance_from_track
+            tt.append(list(vs.times))
+        return out, d2, tt[-1]
+
+    def along(indices, jitter=0.05):
+        p = path[np.asarray(indices) % 100]
+        return p + rng.uniform(-jitter, jitter, p.shape)
+
+    traces = {
+        # forward: two and a half laps from the spawn offset, several steps per point
+        "forward": (np.repeat(np.arange(10, 10 + 260), 3), 10, 2),
+        # backward from the start (crosses 0 -> 99 immediately: reverse start), then forward again past the line twice
+        "reverse_start": (np.concatenate([np.arange(10, -15, -1), np.arange(-15, 130)]), 10, 10),
+        # forward one lap, back across the line, forward again (pop / good_start handling)
+        "back_and_forth": (np.concatenate([np.arange(12, 115), np.arange(115, 105, -1), np.arange(105, 230),
+                                           np.arange(230, 205, -1), np.arange(205, 320)]), 12, 10),
+        # coarse jumps (fast car): 7 points per step
+        "fast_jumps": (np.arange(14, 14 + 7 * 120, 7), 14, 5),
+    }
+    data = {}
+    for name, (idx, offset, target) in traces.items():
+        xy = along(idx)
+        if name == "back_and_forth":   # off-track excursion in the middle: progress frozen while d^2 > 1
+            xy[60:75] += np.array([3.0, 3.0])
+        out, d2, times = run(xy, offset, target)
+        data[f"{name}_xy"] = xy
+        data[f"{name}_out"] = out
+        data[f"{name}_d2"] = d2
+        data[f"{name}_times"] = np.array(times, dtype=np.float64)
+        data[f"{name}_params"] = np.array([offset, target], dtype=np.int64)
+        print("g5:", name, "final laps/completion/good/ntimes/finished/delta/off =", out[-1], "times", np.round(times, 3))
+    data["path"] = path
+    data["dt"] = np.array(dt)
+    np.savez_compressed(os.path.join(HERE, "g5_progress.npz"), **data)
+
+
+if __name__ == "__main__":
+    gen_g1()
+    gen_g2()
+    gen_g3()
+    custom = import_custom()
+    gen_g4(custom)
+    gen_g5()

@@ -1,0 +1,45 @@
+"""Test-side helpers.  The only place (besides bench.py's cpu_baseline leg and smoke()) that loads the oracle."""
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "libftgp_oracle.so")
+
+
+def load_oracle():
+    from ft_grandprix_amd.capi import CLib
+    src = os.path.join(ORACLE_DIR, "ftgp_oracle.c")
+    if not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+    lib = CLib(ORACLE_SO, "oracle_")
+    import ctypes as C
+    d = lib.dll
+    d.oracle_policy_eval.restype = C.c_int
+    d.oracle_policy_eval.argtypes = [C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    d.oracle_fakelidar.restype = C.c_int
+    d.oracle_fakelidar.argtypes = [C.c_double, C.c_double, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                   C.c_double, C.c_void_p, C.c_void_p]
+    d.oracle_quaternion_to_euler.argtypes = [C.c_double] * 4 + [C.c_void_p]
+    d.oracle_euler_to_quaternion.argtypes = [C.c_void_p, C.c_void_p]
+    d.oracle_progress_trace.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    d.oracle_set_lidar_mode.argtypes = [C.c_void_p, C.c_int]
+    d.oracle_set_threads.argtypes = [C.c_void_p, C.c_int]
+    d.oracle_get_field.argtypes = [C.c_void_p, C.c_void_p]
+    return lib
+
+
+def golden(name):
+    return os.path.join(GOLDEN, name)
+
+
+def oracle_policy(lib, policy, scan_f32, last_steer=0.0):
+    import ctypes as C
+    s = np.ascontiguousarray(scan_f32, dtype=np.float32)
+    ls, sp, st = C.c_double(last_steer), C.c_double(), C.c_double()
+    rc = lib.dll.oracle_policy_eval(policy, s.size, s.ctypes.data, C.byref(ls), C.byref(sp), C.byref(st))
+    assert rc == 0
+    return sp.value, st.value, ls.value
