@@ -66,7 +66,7 @@ class FtgpConfig(C.Structure):
 API_SYMBOLS = (
     "default_vehicle", "last_error", "device_count", "create", "destroy", "reset", "set_ctrl", "step",
     "rollout", "get_lidar", "get_snapshot", "get_pose", "get_progress", "get_lap_times", "get_ctrl",
-    "get_steps", "set_pose", "eval_progress", "metrics_local", "comm_unique_id", "comm_init", "metrics_allgather",
+    "get_steps", "set_pose", "policy_eval", "eval_progress", "metrics_local", "comm_unique_id", "comm_init", "metrics_allgather",
     "last_kernel_ms", "kernel_name",
 )
 
@@ -118,6 +118,7 @@ class CLib:
             "get_ctrl": (i32, [vp, dp]),
             "get_steps": (i32, [vp, dp]),
             "set_pose": (i32, [vp, dp]),
+            "policy_eval": (i32, [vp, i32, dp, dp]),
             "eval_progress": (i32, [vp]),
             "metrics_local": (i32, [vp, dp]),
             "device_count": (i32, []),
@@ -246,6 +247,13 @@ class Env:
     def set_pose(self, pose: np.ndarray):
         p = np.ascontiguousarray(pose, dtype=np.float64).reshape(self.n_cars, POSE_DOUBLES)
         self._call("set_pose", _ptr(p))
+
+    def policy_eval(self, policy, ranges: np.ndarray) -> np.ndarray:
+        p = POLICY_BY_NAME[policy] if isinstance(policy, str) else int(policy)
+        r = np.ascontiguousarray(ranges, dtype=np.float32).reshape(self.n_cars, self.n_rays)
+        out = np.empty((self.n_cars, 2), dtype=np.float64)
+        self._call("policy_eval", p, _ptr(r), _ptr(out))
+        return out
 
     def eval_progress(self):
         self._call("eval_progress")

@@ -1,0 +1,567 @@
+// ftgp_api.hip -- implementation of the C-ABI of include/ftgp.h on top of the HIP kernels.
+// Host code only owns resources and launches; there is no CPU compute path (no fallback).
+#include <dlfcn.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "ftgp_kernels.hip"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, const char* a = "")
+{
+    snprintf(g_err, sizeof g_err, fmt, a);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            snprintf(g_err, sizeof g_err, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return FTGP_ERR_HIP;                                                                   \
+        }                                                                                          \
+    } while (0)
+
+// ---- RCCL, loaded lazily so that single-GPU use never touches it ------------------------------
+struct Id128 { char internal[128]; };   // == ncclUniqueId (rccl.h:43)
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, Id128, int) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+constexpr int kNcclFloat64 = 8;          // ncclFloat64 / ncclDouble (rccl.h ncclDataType_t)
+
+Rccl g_rccl;
+
+int load_rccl()
+{
+    if (g_rccl.lib) return 0;
+    void* h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) return fail(FTGP_ERR_COMM, "cannot load librccl.so: %s", dlerror());
+    g_rccl.GetUniqueId = (int (*)(void*))dlsym(h, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (int (*)(void**, int, Id128, int))dlsym(h, "ncclCommInitRank");
+    g_rccl.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(h, "ncclAllGather");
+    g_rccl.CommDestroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
+    g_rccl.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.CommDestroy)
+        return fail(FTGP_ERR_COMM, "librccl.so lacks an expected symbol%s");
+    g_rccl.lib = h;
+    return 0;
+}
+
+}  // namespace
+
+struct FtgpEnv {
+    DeviceParams P{};
+    FtgpConfig cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr, side = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_metrics = nullptr;
+    bool timed = false;
+    // device buffers
+    uint32_t* d_bits = nullptr; uint8_t* d_field = nullptr; double* d_path = nullptr; double* d_spawn = nullptr;
+    float* d_ray_bx = nullptr; float* d_ray_by = nullptr;
+    CarState* d_cars = nullptr; float* d_ranges = nullptr; int64_t* d_steps = nullptr;
+    uint8_t* d_env_mask = nullptr; uint8_t* d_car_mask = nullptr; double* d_ctrl = nullptr; double* d_pose = nullptr;
+    double* d_metrics = nullptr; double* d_gather = nullptr;
+    std::vector<CarState> h_cars;
+    int cars_per_block = 4;
+    bool multi = false;
+    // comm
+    void* comm = nullptr; int rank = 0, world = 1;
+};
+
+namespace {
+
+// exact chessboard distance transform (two raster sweeps over a padded int16 image), clamped to 255
+void build_field(const FtgpTrack& t, std::vector<uint8_t>& out)
+{
+    const int W = t.width, H = t.height, S = W + 2;
+    std::vector<int16_t> d((size_t)S * (H + 2), (int16_t)30000);
+    auto at = [&](int x, int y) -> int16_t& { return d[(size_t)(y + 1) * S + (x + 1)]; };
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x)
+            if ((t.bits[(size_t)y * t.words_per_row + (x >> 5)] >> (x & 31)) & 1u) at(x, y) = 0;
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            int v = at(x, y);
+            int n = std::min(std::min((int)at(x - 1, y), (int)at(x - 1, y - 1)), std::min((int)at(x, y - 1), (int)at(x + 1, y - 1))) + 1;
+            if (n < v) at(x, y) = (int16_t)n;
+        }
+    for (int y = H - 1; y >= 0; --y)
+        for (int x = W - 1; x >= 0; --x) {
+            int v = at(x, y);
+            int n = std::min(std::min((int)at(x + 1, y), (int)at(x + 1, y + 1)), std::min((int)at(x, y + 1), (int)at(x - 1, y + 1))) + 1;
+            if (n < v) at(x, y) = (int16_t)n;
+        }
+    out.resize((size_t)W * H);
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) out[(size_t)y * W + x] = (uint8_t)std::min(255, (int)at(x, y));
+}
+
+int sync_cars_to_host(FtgpEnv* e)
+{
+    HIP_TRY(hipSetDevice(e->device));
+    e->h_cars.resize((size_t)e->P.n_cars);
+    HIP_TRY(hipMemcpyAsync(e->h_cars.data(), e->d_cars, sizeof(CarState) * (size_t)e->P.n_cars, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+int launch_steps(FtgpEnv* e, int policy, int n_steps)
+{
+    if (n_steps < 0) return fail(FTGP_ERR_ARG, "n_steps < 0%s");
+    if ((policy == FTGP_POLICY_NIDC || policy == FTGP_POLICY_FAST) && e->P.n_rays < 8)
+        return fail(FTGP_ERR_ARG, "nidc/fast need n_rays >= 8 (they drop len/8 rays from each end)%s");
+    HIP_TRY(hipSetDevice(e->device));
+    const int cpb = e->cars_per_block;
+    const int blocks = (e->P.n_cars + cpb - 1) / cpb;
+    const bool need_scan = (policy == FTGP_POLICY_NIDC || policy == FTGP_POLICY_FAST);
+    const size_t scan_floats = (size_t)((e->P.n_rays + 3) & ~3);
+    size_t lds = (need_scan ? (size_t)cpb * scan_floats * sizeof(float) : 0) + (e->multi ? (size_t)cpb * sizeof(PubPose) : 0);
+    if (lds > 160 * 1024) return fail(FTGP_ERR_ARG, "scan does not fit LDS%s");
+    HIP_TRY(hipEventRecord(e->ev_start, e->stream));
+    if (n_steps > 0) {
+        if (e->multi) {
+            if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)ftgp_step_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(ftgp_step_kernel<true>, dim3(blocks), dim3(cpb * FTGP_WAVE), lds, e->stream, e->P, policy, n_steps, cpb);
+        } else {
+            if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)ftgp_step_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(ftgp_step_kernel<false>, dim3(blocks), dim3(cpb * FTGP_WAVE), lds, e->stream, e->P, policy, n_steps, cpb);
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(e->ev_stop, e->stream));
+    e->timed = true;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+void ftgp_default_vehicle(FtgpVehicle* v)
+{
+    memset(v, 0, sizeof *v);
+    // masses: chassis 3.542137 (mushr.em.xml:119) + 4 x 0.498952 (:69) + steering-wheel geom 0.01 (:122)
+    // + LiDAR puck (cylinder r 0.03, half-height 0.015, default density 1000; :108) + softeners 4e-5 (:66)
+    v->mass = 5.632768;
+    v->izz = 0.0316994;              // yaw inertia of those parts about the body origin (chassis from the STL volume)
+    const double s = 0.5;            // mushr_scale (:23)
+    v->wheel_x[0] = s * 0.1385;  v->wheel_y[0] = s * 0.115;     // fl (:124)
+    v->wheel_x[1] = s * 0.1385;  v->wheel_y[1] = s * -0.115;    // fr (:137)
+    v->wheel_x[2] = s * -0.158;  v->wheel_y[2] = s * 0.115;     // bl (:150)
+    v->wheel_x[3] = s * -0.158;  v->wheel_y[3] = s * -0.115;    // br (:162)
+    v->wheel_radius = 0.03;
+    v->wheel_inertia = 0.01 + 0.498952 / 5.0 * (0.03 * 0.03 + 0.03 * 0.03);   // armature + ellipsoid about its axle
+    v->wheel_damping = 0.01;
+    v->throttle_kv = 100.0; v->throttle_gear = 0.04; v->throttle_force_limit = 500.0;
+    v->steer_kp = 20.0; v->steer_damping = 0.3;
+    v->steer_inertia = 3 * 0.0002 + 2 * (0.498952 / 5.0 * (0.03 * 0.03 + 0.01 * 0.01)) + 0.01 / 5.0 * (0.03 * 0.03 + 0.01 * 0.01);
+    v->steer_limit = 1.0;
+    v->friction = 0.5; v->gravity = 9.81;
+    v->tire_damping = (v->mass / 4.0) * (2.0 / (0.95 * 0.02));                 // solref 0.02, solimp dmax 0.95 (:69)
+    v->contact_x[0] = 0.0385; v->contact_x[1] = 0.0; v->contact_x[2] = -0.0385;
+    v->contact_radius = 0.0655;
+    v->contact_stiffness = v->mass / (0.95 * 0.95 * 0.02 * 0.02);
+    v->contact_damping = v->mass * (2.0 / (0.95 * 0.02));
+    v->lidar_x = -0.0525; v->lidar_y = 0.0; v->lidar_ring_radius = 0.03;       // (:101-103)
+    v->body_z = 0.0156;
+    v->box_xmin = -0.1027; v->box_xmax = 0.1034; v->box_ymin = -0.0461; v->box_ymax = 0.0472;   // STL bbox x 0.5
+}
+
+const char* ftgp_last_error(void) { return g_err; }
+
+int ftgp_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int ftgp_destroy(FtgpEnv* e)
+{
+    if (!e) return 0;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    if (e->side) (void)hipStreamSynchronize(e->side);
+    if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
+    void* bufs[] = { e->d_bits, e->d_field, e->d_path, e->d_spawn, e->d_ray_bx, e->d_ray_by, e->d_cars, e->d_ranges,
+                     e->d_steps, e->d_env_mask, e->d_car_mask, e->d_ctrl, e->d_pose, e->d_metrics, e->d_gather };
+    for (void* b : bufs) if (b) (void)hipFree(b);
+    if (e->ev_start) (void)hipEventDestroy(e->ev_start);
+    if (e->ev_stop) (void)hipEventDestroy(e->ev_stop);
+    if (e->ev_metrics) (void)hipEventDestroy(e->ev_metrics);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    if (e->side) (void)hipStreamDestroy(e->side);
+    delete e;
+    return 0;
+}
+
+int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
+{
+    if (!cfg || !out) return fail(FTGP_ERR_ARG, "null argument%s");
+    *out = nullptr;
+    if (cfg->abi_version != FTGP_ABI_VERSION) return fail(FTGP_ERR_ARG, "abi version mismatch%s");
+    if (cfg->n_envs < 1 || cfg->cars_per_env < 1 || cfg->cars_per_env > 8 || cfg->n_rays < 1)
+        return fail(FTGP_ERR_ARG, "bad n_envs / cars_per_env / n_rays%s");
+    if (cfg->spawn_mode == 0 && (cfg->cars_per_env + 4) * 2 + 1 >= FTGP_PATH_POINTS)
+        return fail(FTGP_ERR_ARG, "too many cars for the reference spawn rule%s");
+    const FtgpTrack& t = cfg->track;
+    if (t.width < 1 || t.height < 1 || !t.bits || !t.path || t.words_per_row < (t.width + 31) / 32)
+        return fail(FTGP_ERR_ARG, "bad track%s");
+    if (!(cfg->dt > 0.0) || !(t.px_size_x > 0.0) || !(t.px_size_y > 0.0)) return fail(FTGP_ERR_ARG, "bad dt / pixel size%s");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(FTGP_ERR_NO_DEVICE, "no HIP device: this library has no CPU fallback%s");
+    if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(FTGP_ERR_ARG, "device_id out of range%s");
+
+    FtgpEnv* e = new FtgpEnv();
+    e->cfg = *cfg;
+    e->device = cfg->device_id;
+#define CREATE_TRY(expr)                                                                           \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            snprintf(g_err, sizeof g_err, "%s failed: %s", #expr, hipGetErrorString(e_));          \
+            ftgp_destroy(e);                                                                       \
+            return FTGP_ERR_HIP;                                                                   \
+        }                                                                                          \
+    } while (0)
+    CREATE_TRY(hipSetDevice(e->device));
+    CREATE_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    CREATE_TRY(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+    CREATE_TRY(hipEventCreate(&e->ev_start));
+    CREATE_TRY(hipEventCreate(&e->ev_stop));
+    CREATE_TRY(hipEventCreateWithFlags(&e->ev_metrics, hipEventDisableTiming));
+
+    DeviceParams& P = e->P;
+    P.n_envs = cfg->n_envs; P.cars_per_env = cfg->cars_per_env; P.n_cars = cfg->n_envs * cfg->cars_per_env;
+    P.n_rays = cfg->n_rays; P.lap_target = cfg->lap_target; P.spawn_mode = cfg->spawn_mode;
+    P.ranges_stride = (cfg->n_rays + 63) & ~63;      // rows start on 256-B boundaries: every pass is one aligned store
+    P.seed = cfg->seed; P.dt = cfg->dt;
+    P.width = t.width; P.height = t.height; P.words_per_row = t.words_per_row;
+    P.px_size_x = t.px_size_x; P.px_size_y = t.px_size_y; P.origin_x = t.origin_x; P.origin_y = t.origin_y;
+    P.inv_px_x = 1.0 / t.px_size_x; P.inv_px_y = 1.0 / t.px_size_y;
+    P.inv_px_x_f = (float)P.inv_px_x; P.inv_px_y_f = (float)P.inv_px_y;
+    P.veh = cfg->vehicle;
+    const FtgpVehicle& v = cfg->vehicle;
+    {   // static wheel loads from the wheelbase split
+        const double a_f = 0.5 * (v.wheel_x[0] + v.wheel_x[1]), a_r = -0.5 * (v.wheel_x[2] + v.wheel_x[3]);
+        const double wtot = v.mass * v.gravity;
+        P.wheel_load[0] = P.wheel_load[1] = 0.5 * (wtot * (a_r / (a_f + a_r)));
+        P.wheel_load[2] = P.wheel_load[3] = 0.5 * (wtot * (a_f / (a_f + a_r)));
+    }
+    e->multi = cfg->cars_per_env > 1;
+    e->cars_per_block = e->multi ? cfg->cars_per_env : 4;
+    if (!e->multi) {
+        if (const char* s = getenv("FTGP_CARS_PER_BLOCK")) { int c = atoi(s); if (c >= 1 && c <= 8) e->cars_per_block = c; }
+    }
+
+    // host-side tables
+    std::vector<uint8_t> field;
+    build_field(t, field);
+    std::vector<float> bx(cfg->n_rays), by(cfg->n_rays);
+    for (int j = 0; j < cfg->n_rays; ++j) {
+        // mushr.em.xml:112-117: phi_j = radians(360/R*j - 90); the ray (+z of the site) is (sin phi, -cos phi, 0)
+        const double phi = ((360.0 / (double)cfg->n_rays) * (double)j - 90.0) * (M_PI / 180.0);
+        bx[j] = (float)sin(phi); by[j] = (float)(-cos(phi));
+    }
+    std::vector<double> spawn(4 * FTGP_PATH_POINTS);
+    for (int p = 0; p < FTGP_PATH_POINTS; ++p) {
+        // position_vehicles (custom.py:1240-1245) + euler_to_quaternion([angle, 0, 0]) (custom.py:81-87)
+        const int p1 = (p + 1) % FTGP_PATH_POINTS;
+        const double ang = atan2(t.path[2 * p1 + 1] - t.path[2 * p + 1], t.path[2 * p1] - t.path[2 * p]);
+        spawn[4 * p] = t.path[2 * p]; spawn[4 * p + 1] = t.path[2 * p + 1];
+        spawn[4 * p + 2] = cos(ang / 2); spawn[4 * p + 3] = sin(ang / 2);
+    }
+
+    const size_t nbits = (size_t)t.height * t.words_per_row;
+    CREATE_TRY(hipMalloc(&e->d_bits, nbits * 4));
+    CREATE_TRY(hipMalloc(&e->d_field, field.size()));
+    CREATE_TRY(hipMalloc(&e->d_path, sizeof(double) * 2 * FTGP_PATH_POINTS));
+    CREATE_TRY(hipMalloc(&e->d_spawn, sizeof(double) * 4 * FTGP_PATH_POINTS));
+    CREATE_TRY(hipMalloc(&e->d_ray_bx, sizeof(float) * cfg->n_rays));
+    CREATE_TRY(hipMalloc(&e->d_ray_by, sizeof(float) * cfg->n_rays));
+    CREATE_TRY(hipMalloc(&e->d_cars, sizeof(CarState) * (size_t)P.n_cars));
+    CREATE_TRY(hipMalloc(&e->d_ranges, sizeof(float) * (size_t)P.n_cars * P.ranges_stride));
+    CREATE_TRY(hipMalloc(&e->d_steps, sizeof(int64_t) * (size_t)P.n_envs));
+    CREATE_TRY(hipMalloc(&e->d_env_mask, (size_t)P.n_envs));
+    CREATE_TRY(hipMalloc(&e->d_car_mask, (size_t)P.n_cars));
+    CREATE_TRY(hipMalloc(&e->d_ctrl, sizeof(double) * 2 * (size_t)P.n_cars));
+    CREATE_TRY(hipMalloc(&e->d_pose, sizeof(double) * FTGP_POSE_DOUBLES * (size_t)P.n_cars));
+    CREATE_TRY(hipMalloc(&e->d_metrics, sizeof(double) * FTGP_METRIC_DOUBLES));
+    CREATE_TRY(hipMemcpy(e->d_bits, t.bits, nbits * 4, hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemcpy(e->d_field, field.data(), field.size(), hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemcpy(e->d_path, t.path, sizeof(double) * 2 * FTGP_PATH_POINTS, hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemcpy(e->d_spawn, spawn.data(), sizeof(double) * spawn.size(), hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemcpy(e->d_ray_bx, bx.data(), sizeof(float) * bx.size(), hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemcpy(e->d_ray_by, by.data(), sizeof(float) * by.size(), hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemset(e->d_ranges, 0, sizeof(float) * (size_t)P.n_cars * P.ranges_stride));
+    CREATE_TRY(hipMemset(e->d_steps, 0, sizeof(int64_t) * (size_t)P.n_envs));
+    P.bits = e->d_bits; P.field = e->d_field; P.path = e->d_path; P.spawn = e->d_spawn;
+    P.ray_bx = e->d_ray_bx; P.ray_by = e->d_ray_by; P.cars = e->d_cars; P.ranges = e->d_ranges; P.steps = e->d_steps;
+#undef CREATE_TRY
+    int rc = ftgp_reset(e, nullptr);
+    if (rc != 0) { ftgp_destroy(e); return rc; }
+    *out = e;
+    return 0;
+}
+
+int ftgp_reset(FtgpEnv* e, const uint8_t* mask)
+{
+    if (!e) return fail(FTGP_ERR_ARG, "null handle%s");
+    HIP_TRY(hipSetDevice(e->device));
+    const uint8_t* dmask = nullptr;
+    if (mask) {
+        HIP_TRY(hipMemcpyAsync(e->d_env_mask, mask, (size_t)e->P.n_envs, hipMemcpyHostToDevice, e->stream));
+        dmask = e->d_env_mask;
+    }
+    hipLaunchKernelGGL(ftgp_reset_kernel, dim3((e->P.n_cars + 63) / 64), dim3(64), 0, e->stream, e->P, dmask);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+int ftgp_set_ctrl(FtgpEnv* e, const double* ctrl, const uint8_t* car_mask)
+{
+    if (!e || !ctrl) return fail(FTGP_ERR_ARG, "null argument%s");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipMemcpyAsync(e->d_ctrl, ctrl, sizeof(double) * 2 * (size_t)e->P.n_cars, hipMemcpyHostToDevice, e->stream));
+    const uint8_t* dmask = nullptr;
+    if (car_mask) {
+        HIP_TRY(hipMemcpyAsync(e->d_car_mask, car_mask, (size_t)e->P.n_cars, hipMemcpyHostToDevice, e->stream));
+        dmask = e->d_car_mask;
+    }
+    hipLaunchKernelGGL(ftgp_set_ctrl_kernel, dim3((e->P.n_cars + 255) / 256), dim3(256), 0, e->stream, e->P, e->d_ctrl, dmask);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(e->stream));   // the caller's buffers may be reused as soon as we return
+    return 0;
+}
+
+int ftgp_step(FtgpEnv* e, int n_steps)
+{
+    if (!e) return fail(FTGP_ERR_ARG, "null handle%s");
+    return launch_steps(e, FTGP_POLICY_HOST, n_steps);
+}
+
+int ftgp_rollout(FtgpEnv* e, int policy, int n_steps)
+{
+    if (!e) return fail(FTGP_ERR_ARG, "null handle%s");
+    if (policy < FTGP_POLICY_HOST || policy > FTGP_POLICY_RANDOM) return fail(FTGP_ERR_ARG, "unknown policy%s");
+    return launch_steps(e, policy, n_steps);
+}
+
+int ftgp_get_lidar(FtgpEnv* e, float* out)
+{
+    if (!e || !out) return fail(FTGP_ERR_ARG, "null argument%s");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipMemcpy2DAsync(out, sizeof(float) * (size_t)e->P.n_rays, e->d_ranges, sizeof(float) * (size_t)e->P.ranges_stride,
+                             sizeof(float) * (size_t)e->P.n_rays, (size_t)e->P.n_cars, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+static inline int lap_completion_of(const CarState& a) { return a.good_start ? a.completion : -(100 - a.completion); }
+
+int ftgp_get_snapshot(FtgpEnv* e, double* out)
+{
+    if (!e || !out) return fail(FTGP_ERR_ARG, "null argument%s");
+    if (int rc = sync_cars_to_host(e)) return rc;
+    std::vector<int64_t> steps((size_t)e->P.n_envs);
+    HIP_TRY(hipMemcpy(steps.data(), e->d_steps, sizeof(int64_t) * steps.size(), hipMemcpyDeviceToHost));
+    for (int i = 0; i < e->P.n_cars; ++i) {
+        const CarState& a = e->h_cars[(size_t)i];
+        double* o = out + (size_t)i * FTGP_SNAPSHOT_DOUBLES;
+        // quaternion_to_euler(w, 0, 0, z), custom.py:62-76
+        const double w = a.qw, x = 0.0, y = 0.0, z = a.qz;
+        const double roll = atan2(+2.0 * (w * x + y * z), +1.0 - 2.0 * (x * x + y * y));
+        double t2 = +2.0 * (w * y - z * x);
+        t2 = t2 > +1.0 ? +1.0 : t2; t2 = t2 < -1.0 ? -1.0 : t2;
+        const double pitch = asin(t2);
+        const double yaw = atan2(+2.0 * (w * z + x * y), +1.0 - 2.0 * (y * y + z * z));
+        const int lc = lap_completion_of(a);
+        o[0] = a.laps; o[1] = a.vx; o[2] = a.vy; o[3] = 0.0; o[4] = yaw; o[5] = pitch; o[6] = roll;
+        o[7] = lc; o[8] = a.laps * 100 + lc;
+        o[9] = (double)steps[(size_t)(i / e->P.cars_per_env)] / e->P.dt;   // time = steps / timestep, custom.py:1397 (sic)
+    }
+    return 0;
+}
+
+int ftgp_get_pose(FtgpEnv* e, double* out)
+{
+    if (!e || !out) return fail(FTGP_ERR_ARG, "null argument%s");
+    if (int rc = sync_cars_to_host(e)) return rc;
+    for (int i = 0; i < e->P.n_cars; ++i) {
+        const CarState& a = e->h_cars[(size_t)i];
+        double* o = out + (size_t)i * FTGP_POSE_DOUBLES;
+        o[0] = a.x; o[1] = a.y; o[2] = e->P.veh.body_z; o[3] = a.qw; o[4] = 0; o[5] = 0; o[6] = a.qz;
+        o[7] = a.vx; o[8] = a.vy; o[9] = 0; o[10] = 0; o[11] = 0; o[12] = a.wz;
+    }
+    return 0;
+}
+
+int ftgp_set_pose(FtgpEnv* e, const double* pose)
+{
+    if (!e || !pose) return fail(FTGP_ERR_ARG, "null argument%s");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipMemcpyAsync(e->d_pose, pose, sizeof(double) * FTGP_POSE_DOUBLES * (size_t)e->P.n_cars, hipMemcpyHostToDevice, e->stream));
+    hipLaunchKernelGGL(ftgp_set_pose_kernel, dim3((e->P.n_cars + 255) / 256), dim3(256), 0, e->stream, e->P, e->d_pose);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+int ftgp_policy_eval(FtgpEnv* e, int policy, const float* ranges, double* ctrl_out)
+{
+    if (!e || !ranges) return fail(FTGP_ERR_ARG, "null argument%s");
+    if (policy < FTGP_POLICY_LOBOTOMY || policy > FTGP_POLICY_RANDOM) return fail(FTGP_ERR_ARG, "policy_eval: device policies only%s");
+    if ((policy == FTGP_POLICY_NIDC || policy == FTGP_POLICY_FAST) && e->P.n_rays < 8)
+        return fail(FTGP_ERR_ARG, "nidc/fast need n_rays >= 8%s");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipMemcpy2DAsync(e->d_ranges, sizeof(float) * (size_t)e->P.ranges_stride, ranges, sizeof(float) * (size_t)e->P.n_rays,
+                             sizeof(float) * (size_t)e->P.n_rays, (size_t)e->P.n_cars, hipMemcpyHostToDevice, e->stream));
+    const size_t lds = 4 * (size_t)((e->P.n_rays + 3) & ~3) * sizeof(float);
+    if (lds > 64 * 1024) return fail(FTGP_ERR_ARG, "scan does not fit LDS%s");
+    hipLaunchKernelGGL(ftgp_policy_kernel, dim3((e->P.n_cars + 3) / 4), dim3(256), lds, e->stream, e->P, policy, ctrl_out ? e->d_ctrl : nullptr);
+    HIP_TRY(hipGetLastError());
+    if (ctrl_out) HIP_TRY(hipMemcpyAsync(ctrl_out, e->d_ctrl, sizeof(double) * 2 * (size_t)e->P.n_cars, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+int ftgp_eval_progress(FtgpEnv* e)
+{
+    if (!e) return fail(FTGP_ERR_ARG, "null handle%s");
+    HIP_TRY(hipSetDevice(e->device));
+    hipLaunchKernelGGL(ftgp_progress_kernel, dim3((e->P.n_cars + 63) / 64), dim3(64), 0, e->stream, e->P);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int ftgp_get_progress(FtgpEnv* e, int32_t* out)
+{
+    if (!e || !out) return fail(FTGP_ERR_ARG, "null argument%s");
+    if (int rc = sync_cars_to_host(e)) return rc;
+    for (int i = 0; i < e->P.n_cars; ++i) {
+        const CarState& a = e->h_cars[(size_t)i];
+        int32_t* o = out + (size_t)i * FTGP_PROGRESS_INTS;
+        const int lc = lap_completion_of(a);
+        o[0] = a.laps; o[1] = a.completion; o[2] = lc; o[3] = a.laps * 100 + lc; o[4] = a.finished;
+        o[5] = a.off_track; o[6] = a.start; o[7] = a.good_start; o[8] = a.delta;
+    }
+    return 0;
+}
+
+int ftgp_get_lap_times(FtgpEnv* e, int32_t* counts, double* times)
+{
+    if (!e || !counts || !times) return fail(FTGP_ERR_ARG, "null argument%s");
+    if (int rc = sync_cars_to_host(e)) return rc;
+    for (int i = 0; i < e->P.n_cars; ++i) {
+        counts[i] = e->h_cars[(size_t)i].n_times;
+        memcpy(times + (size_t)i * FTGP_MAX_LAP_TIMES, e->h_cars[(size_t)i].times, sizeof(double) * FTGP_MAX_LAP_TIMES);
+    }
+    return 0;
+}
+
+int ftgp_get_ctrl(FtgpEnv* e, double* out)
+{
+    if (!e || !out) return fail(FTGP_ERR_ARG, "null argument%s");
+    if (int rc = sync_cars_to_host(e)) return rc;
+    for (int i = 0; i < e->P.n_cars; ++i) { out[2 * i] = e->h_cars[(size_t)i].u_speed; out[2 * i + 1] = e->h_cars[(size_t)i].u_steer; }
+    return 0;
+}
+
+int ftgp_get_steps(FtgpEnv* e, int64_t* out)
+{
+    if (!e || !out) return fail(FTGP_ERR_ARG, "null argument%s");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipMemcpyAsync(out, e->d_steps, sizeof(int64_t) * (size_t)e->P.n_envs, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+int ftgp_metrics_local(FtgpEnv* e, double* out)
+{
+    if (!e || !out) return fail(FTGP_ERR_ARG, "null argument%s");
+    HIP_TRY(hipSetDevice(e->device));
+    hipLaunchKernelGGL(ftgp_metrics_kernel, dim3(1), dim3(256), 0, e->stream, e->P, e->d_metrics);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, e->d_metrics, sizeof(double) * FTGP_METRIC_DOUBLES, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+int ftgp_comm_unique_id(uint8_t id_out[128])
+{
+    if (!id_out) return fail(FTGP_ERR_ARG, "null argument%s");
+    if (int rc = load_rccl()) return rc;
+    Id128 id;
+    int r = g_rccl.GetUniqueId(&id);
+    if (r != 0) return fail(FTGP_ERR_COMM, "ncclGetUniqueId: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    memcpy(id_out, id.internal, 128);
+    return 0;
+}
+
+int ftgp_comm_init(FtgpEnv* e, const uint8_t id[128], int rank, int world_size)
+{
+    if (!e || !id || world_size < 1 || rank < 0 || rank >= world_size) return fail(FTGP_ERR_ARG, "bad comm arguments%s");
+    if (int rc = load_rccl()) return rc;
+    HIP_TRY(hipSetDevice(e->device));
+    Id128 uid; memcpy(uid.internal, id, 128);
+    int r = g_rccl.CommInitRank(&e->comm, world_size, uid, rank);
+    if (r != 0) return fail(FTGP_ERR_COMM, "ncclCommInitRank: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    e->rank = rank; e->world = world_size;
+    HIP_TRY(hipMalloc(&e->d_gather, sizeof(double) * FTGP_METRIC_DOUBLES * (size_t)world_size));
+    return 0;
+}
+
+int ftgp_metrics_allgather(FtgpEnv* e, double* out)
+{
+    if (!e || !out) return fail(FTGP_ERR_ARG, "null argument%s");
+    HIP_TRY(hipSetDevice(e->device));
+    // reduce on the compute stream (it reads the state the step kernel wrote), gather on the side stream
+    hipLaunchKernelGGL(ftgp_metrics_kernel, dim3(1), dim3(256), 0, e->stream, e->P, e->d_metrics);
+    HIP_TRY(hipGetLastError());
+    if (!e->comm || e->world == 1) {
+        HIP_TRY(hipMemcpyAsync(out, e->d_metrics, sizeof(double) * FTGP_METRIC_DOUBLES, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        return 0;
+    }
+    HIP_TRY(hipEventRecord(e->ev_metrics, e->stream));
+    HIP_TRY(hipStreamWaitEvent(e->side, e->ev_metrics, 0));
+    int r = g_rccl.AllGather(e->d_metrics, e->d_gather, FTGP_METRIC_DOUBLES, kNcclFloat64, e->comm, e->side);
+    if (r != 0) return fail(FTGP_ERR_COMM, "ncclAllGather: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    HIP_TRY(hipMemcpyAsync(out, e->d_gather, sizeof(double) * FTGP_METRIC_DOUBLES * (size_t)e->world, hipMemcpyDeviceToHost, e->side));
+    HIP_TRY(hipStreamSynchronize(e->side));
+    return 0;
+}
+
+int ftgp_last_kernel_ms(FtgpEnv* e, float* ms)
+{
+    if (!e || !ms) return fail(FTGP_ERR_ARG, "null argument%s");
+    if (!e->timed) return fail(FTGP_ERR_STATE, "no step/rollout has been launched yet%s");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipEventSynchronize(e->ev_stop));
+    HIP_TRY(hipEventElapsedTime(ms, e->ev_start, e->ev_stop));
+    return 0;
+}
+
+const char* ftgp_kernel_name(FtgpEnv* e)
+{
+    return (e && e->multi) ? "ftgp_step_kernel<true>" : "ftgp_step_kernel<false>";
+}
+
+}  // extern "C"

@@ -1,0 +1,653 @@
+// ftgp_kernels.hip -- HIP kernels of the ft_grandprix hot path for gfx950 (CDNA4, wave64).
+//
+//   ftgp_step_kernel   K5 policy -> K2 LiDAR sweep -> K1 integrate -> K3 lap progress, n_steps per launch.
+//                      One wave per car: the 64 lanes stride the car's rays (coalesced 256-B range stores),
+//                      the car's state lives in wave-uniform registers across all steps of the launch, the
+//                      previous scan is staged in LDS for the on-device driver, contact candidates and the
+//                      centre-line argmin are spread over lanes and resolved with wave reductions.
+//   ftgp_reset_kernel  K4 reset / spawn (+ progress at the spawn pose), one car per lane.
+//   ftgp_progress_kernel  K3 alone (after ftgp_set_pose), one car per lane.
+//   ftgp_metrics_kernel   per-GPU metrics record.
+//
+// Reference behaviour restated by each block is cited inline (paths relative to the reference repo).
+// The arithmetic follows the specification in DESIGN.md operation by operation (-ffp-contract=off; explicit
+// fmaf where the specification says "fma") so that results are bit-identical to the CPU oracle.
+#include "ftgp_device.h"
+
+// =============================================================================================
+// K2: LiDAR
+// =============================================================================================
+
+// Variable-step DDA over the chessboard distance field: from cell (ix, iy) with field value k the
+// (2k-1)^2 block of cells around it is wall-free, so the ray jumps straight to that block's boundary.
+// With k == 1 this is the classic cell-by-cell DDA.
+__device__ __forceinline__ float march_f32(const DeviceParams& P, float pu, float pv, float du, float dv)
+{
+    const int W = P.width, H = P.height;
+    int ix = (int)floorf(pu), iy = (int)floorf(pv);
+    if (ix < 0 || ix >= W || iy < 0 || iy >= H) return -1.0f;
+    const bool xnz = du != 0.0f, ynz = dv != 0.0f;
+    const bool xpos = du > 0.0f, ypos = dv > 0.0f;
+    const float inv_du = xnz ? 1.0f / du : 0.0f;
+    const float inv_dv = ynz ? 1.0f / dv : 0.0f;
+    const uint8_t* __restrict__ field = P.field;
+    float s = 0.0f;
+    for (int it = 0; it < 8192; ++it) {
+        const int k = field[iy * W + ix];
+        if (k == 0) return s;
+        const int bxi = xpos ? ix + k : ix - k + 1;
+        const int byi = ypos ? iy + k : iy - k + 1;
+        const float sX = xnz ? ((float)bxi - pu) * inv_du : INFINITY;
+        const float sY = ynz ? ((float)byi - pv) * inv_dv : INFINITY;
+        if (sX < sY) {
+            s = sX;
+            const int nix = xpos ? ix + k : ix - k;
+            int t = (int)floorf(fmaf(dv, s, pv));
+            const int lo = iy - k + 1, hi = iy + k - 1;
+            iy = t < lo ? lo : (t > hi ? hi : t);
+            ix = nix;
+        } else {
+            s = sY;
+            const int niy = ypos ? iy + k : iy - k;
+            int t = (int)floorf(fmaf(du, s, pu));
+            const int lo = ix - k + 1, hi = ix + k - 1;
+            ix = t < lo ? lo : (t > hi ? hi : t);
+            iy = niy;
+        }
+        if (ix < 0 || ix >= W || iy < 0 || iy >= H) return -1.0f;
+    }
+    return -1.0f;
+}
+
+// Pose of a car as seen by the other cars of its env (pre-step state, published through LDS).
+struct PubPose { double x, y, qw, qz, vx, vy, wz, pad; };
+
+// Ray against another car: chassis box (slab test) and LiDAR puck (circle), binary32.
+__device__ __forceinline__ float ray_vs_car(const FtgpVehicle& v, const PubPose& b, double lcx, double lcy, float dxw, float dyw)
+{
+    const float r0 = (float)v.lidar_ring_radius;
+    float best = INFINITY;
+    const double cb = 1.0 - 2.0 * (b.qz * b.qz), sb = 2.0 * (b.qw * b.qz);
+    const float relx = (float)(lcx - b.x), rely = (float)(lcy - b.y);
+    const float ox = fmaf(dxw, -r0, relx), oy = fmaf(dyw, -r0, rely);
+    const float cbf = (float)cb, sbf = (float)sb;
+    const float lx = fmaf(cbf, ox, sbf * oy), ly = fmaf(cbf, oy, -(sbf * ox));
+    const float ldx = fmaf(cbf, dxw, sbf * dyw), ldy = fmaf(cbf, dyw, -(sbf * dxw));
+    {
+        const float xmin = (float)v.box_xmin, xmax = (float)v.box_xmax, ymin = (float)v.box_ymin, ymax = (float)v.box_ymax;
+        float tmin = -INFINITY, tmax = INFINITY; bool miss = false;
+        if (ldx != 0.0f) {
+            const float inv = 1.0f / ldx; const float t1 = (xmin - lx) * inv, t2 = (xmax - lx) * inv;
+            tmin = fmaxf(tmin, fminf(t1, t2)); tmax = fminf(tmax, fmaxf(t1, t2));
+        } else if (lx < xmin || lx > xmax) miss = true;
+        if (ldy != 0.0f) {
+            const float inv = 1.0f / ldy; const float t1 = (ymin - ly) * inv, t2 = (ymax - ly) * inv;
+            tmin = fmaxf(tmin, fminf(t1, t2)); tmax = fminf(tmax, fmaxf(t1, t2));
+        } else if (ly < ymin || ly > ymax) miss = true;
+        if (!miss && tmax >= fmaxf(tmin, 0.0f)) {
+            const float t = tmin > 0.0f ? tmin : 0.0f;
+            if (t < best) best = t;
+        }
+    }
+    {
+        const float px = lx - (float)v.lidar_x, py = ly - (float)v.lidar_y;
+        const float bq = fmaf(px, ldx, py * ldy);
+        const float cq = fmaf(px, px, py * py) - r0 * r0;
+        const float disc = fmaf(bq, bq, -cq);
+        if (disc >= 0.0f) {
+            float t = -bq - sqrtf(disc);
+            if (t < 0.0f) t = (cq < 0.0f) ? 0.0f : INFINITY;
+            if (t < best) best = t;
+        }
+    }
+    return best;
+}
+
+// Full sweep of one car by one wave.  Rangefinder geometry: template/mushr.em.xml:98-117 -- ray j leaves
+// the ring at centre - 0.03*dir_j, dir_j = R(yaw) * (sin phi_j, -cos phi_j); j = 0 is the rear, CCW.
+// Values replace data.sensordata[vehicle_state.sensors] (custom.py:1395).
+template <bool MULTI>
+__device__ __forceinline__ void lidar_sweep(const DeviceParams& P, const CarCore& s, float* __restrict__ out_global,
+                                            float* __restrict__ out_lds, const PubPose* pub, int my_slot)
+{
+    const FtgpVehicle& v = P.veh;
+    const double ch = 1.0 - 2.0 * (s.qz * s.qz), sh = 2.0 * (s.qw * s.qz);
+    const double lcx = s.x + (ch * v.lidar_x - sh * v.lidar_y);
+    const double lcy = s.y + (sh * v.lidar_x + ch * v.lidar_y);
+    const float u0 = (float)((lcx - P.origin_x) * P.inv_px_x);
+    const float v0 = (float)((P.origin_y - lcy) * P.inv_px_y);
+    const float chf = (float)ch, shf = (float)sh;
+    const float isx = P.inv_px_x_f, isy = P.inv_px_y_f;
+    const float r0 = (float)v.lidar_ring_radius;
+    const int R = P.n_rays;
+    const int lane = lane_id();
+    for (int base = 0; base < R; base += FTGP_WAVE) {
+        const int j = base + lane;
+        if (j < R) {
+            const float bx = P.ray_bx[j], by = P.ray_by[j];
+            const float dxw = fmaf(chf, bx, -(shf * by));
+            const float dyw = fmaf(shf, bx, chf * by);
+            const float du = dxw * isx;
+            const float dv = -(dyw * isy);
+            const float pu = fmaf(du, -r0, u0);
+            const float pv = fmaf(dv, -r0, v0);
+            float r = march_f32(P, pu, pv, du, dv);
+            if (MULTI) {
+                for (int k = 0; k < P.cars_per_env; ++k) {
+                    if (k == my_slot) continue;
+                    const float rc = ray_vs_car(v, pub[k], lcx, lcy, dxw, dyw);
+                    if (rc < INFINITY && (r < 0.0f || rc < r)) r = rc;
+                }
+            }
+            out_global[j] = r;
+            if (out_lds) out_lds[j] = r;
+        }
+    }
+}
+
+// =============================================================================================
+// K3: lap progress (custom.py:1340-1372), wave-cooperative argmin over the 100 centre-line points
+// =============================================================================================
+__device__ __forceinline__ void progress_update(const DeviceParams& P, CarCore& s, int64_t steps, int closest, double best, double* __restrict__ times)
+{
+    s.dist2 = best;                                       // custom.py:1343 (squared)
+    s.off_track = best > 1.0;                             // custom.py:1344
+    if (s.off_track) return;                              // custom.py:1345: progress frozen off-track
+    const int completion = ((closest - s.offset) % 100 + 100) % 100;
+    const int delta = completion - s.completion;
+    s.delta = (((completion - s.completion + 50) % 100) + 100) % 100 - 50;
+    if (abs(delta) > 90) {
+        const double lap_time = (double)(steps - (int64_t)s.start) * P.dt;
+        if (s.delta < 0) {                                // backwards across the line, custom.py:1352-1356
+            s.laps -= 1;
+            s.good_start = 0;
+            if (s.n_times != 0) s.n_times -= 1;
+        } else if (s.delta > 0) {                         // custom.py:1357-1366
+            if (s.good_start) {
+                if (s.n_times < FTGP_MAX_LAP_TIMES) times[s.n_times] = lap_time;
+                s.n_times += 1;
+                s.start = (int32_t)steps;
+            }
+            s.laps += 1;
+            s.good_start = 1;
+        }
+    }
+    if (s.laps >= P.lap_target) s.finished = 1;           // custom.py:1367-1370
+    s.completion = completion;
+}
+
+__device__ __forceinline__ void progress_wave(const DeviceParams& P, CarCore& s, int64_t steps, double* __restrict__ times)
+{
+    const int lane = lane_id();
+    // distances = ((path - xpos)**2).sum(1); closest = distances.argmin()   (first minimum)
+    double best = INFINITY; int idx = 0x7fffffff;
+    #pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int i = lane + h * FTGP_WAVE;
+        if (i < FTGP_PATH_POINTS) {
+            const double dx = P.path[2 * i] - s.x, dy = P.path[2 * i + 1] - s.y;
+            const double d = dx * dx + dy * dy;
+            if (d < best) { best = d; idx = i; }
+        }
+    }
+    #pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const double ob = shfl_xor_f64(best, m);
+        const int oi = __shfl_xor(idx, m, FTGP_WAVE);
+        if (ob < best || (ob == best && oi < idx)) { best = ob; idx = oi; }
+    }
+    progress_update(P, s, steps, idx, best, times);
+}
+
+// =============================================================================================
+// K1: integrate one dt (reduced planar model of template/mushr.em.xml stepped by mj_step, custom.py:1425)
+// =============================================================================================
+struct Force { double fx, fy, tz; };
+
+// Chassis circles against wall pixels: the (2nx+1) x (2ny+1) candidate cells of each circle are tested
+// one per lane; the deepest penetration (ties: first in raster order) is picked by a wave reduction.
+__device__ __forceinline__ void wall_contact(const DeviceParams& P, const CarCore& s, double ch, double sh, Force& f)
+{
+    const FtgpVehicle& v = P.veh;
+    const int W = P.width, H = P.height;
+    const double sx = P.px_size_x, sy = P.px_size_y;
+    const double r = v.contact_radius;
+    const int nx = (int)ceil(r * P.inv_px_x), ny = (int)ceil(r * P.inv_px_y);
+    const int reach = (nx > ny ? nx : ny) + 1;
+    const int wx = 2 * nx + 1, ncell = wx * (2 * ny + 1);
+    const int lane = lane_id();
+    for (int k = 0; k < 3; ++k) {
+        const double rxw = ch * v.contact_x[k], ryw = sh * v.contact_x[k];
+        const double px = s.x + rxw, py = s.y + ryw;
+        const double u = (px - P.origin_x) * P.inv_px_x, w = (P.origin_y - py) * P.inv_px_y;
+        const int ix = (int)floor(u), iy = (int)floor(w);
+        if (ix < 0 || ix >= W || iy < 0 || iy >= H) continue;
+        if ((int)P.field[iy * W + ix] > reach) continue;
+        double mypen = 0.0; int myc = 0x7fffffff;
+        for (int base = 0; base < ncell; base += FTGP_WAVE) {
+            const int c = base + lane;
+            if (c < ncell) {
+                const int cy = iy + (c / wx - ny), cx = ix + (c % wx - nx);
+                if (cx >= 0 && cx < W && cy >= 0 && cy < H &&
+                    ((P.bits[cy * P.words_per_row + (cx >> 5)] >> (cx & 31)) & 1u)) {
+                    const double x0 = P.origin_x + (double)cx * sx, x1 = x0 + sx;
+                    const double y1 = P.origin_y - (double)cy * sy, y0 = y1 - sy;
+                    const double qx = px < x0 ? x0 : (px > x1 ? x1 : px);
+                    const double qy = py < y0 ? y0 : (py > y1 ? y1 : py);
+                    const double ex = px - qx, ey = py - qy;
+                    const double d2 = ex * ex + ey * ey;
+                    if (d2 < r * r) {
+                        const double pen = r - sqrt(d2);
+                        if (pen > mypen) { mypen = pen; myc = c; }
+                    }
+                }
+            }
+        }
+        #pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const double op = shfl_xor_f64(mypen, m);
+            const int oc = __shfl_xor(myc, m, FTGP_WAVE);
+            if (op > mypen || (op == mypen && oc < myc)) { mypen = op; myc = oc; }
+        }
+        if (!(mypen > 0.0)) continue;
+        // winner, recomputed wave-uniformly
+        const int cy = iy + (myc / wx - ny), cx = ix + (myc % wx - nx);
+        const double x0 = P.origin_x + (double)cx * sx, x1 = x0 + sx;
+        const double y1 = P.origin_y - (double)cy * sy, y0 = y1 - sy;
+        const double qx = px < x0 ? x0 : (px > x1 ? x1 : px);
+        const double qy = py < y0 ? y0 : (py > y1 ? y1 : py);
+        const double ex = px - qx, ey = py - qy;
+        const double d = sqrt(ex * ex + ey * ey);
+        double nxv, nyv;
+        if (d > 0.0) { nxv = ex / d; nyv = ey / d; }
+        else {
+            const double mx = px - (x0 + 0.5 * sx), my = py - (y0 + 0.5 * sy);
+            const double mm = sqrt(mx * mx + my * my);
+            if (mm > 0.0) { nxv = mx / mm; nyv = my / mm; } else { nxv = 0.0; nyv = 0.0; }
+        }
+        const double vcx = s.vx - s.wz * ryw, vcy = s.vy + s.wz * rxw;
+        const double vn = vcx * nxv + vcy * nyv;
+        const double mag = v.contact_stiffness * mypen - v.contact_damping * vn;
+        if (mag <= 0.0) continue;
+        const double fx = mag * nxv, fy = mag * nyv;
+        f.fx += fx; f.fy += fy; f.tz += rxw * fy - ryw * fx;
+    }
+}
+
+// Circles of this car against the circles of the other cars of the env (penalty spring/damper).
+__device__ __forceinline__ void car_contact(const DeviceParams& P, const CarCore& s, double ch, double sh,
+                                            const PubPose* pub, int my_slot, Force& f)
+{
+    const FtgpVehicle& v = P.veh;
+    const double r2 = 2.0 * v.contact_radius;
+    for (int k = 0; k < P.cars_per_env; ++k) {
+        if (k == my_slot) continue;
+        const PubPose b = pub[k];
+        const double cb = 1.0 - 2.0 * (b.qz * b.qz), sb = 2.0 * (b.qw * b.qz);
+        for (int i = 0; i < 3; ++i) {
+            const double rxw = ch * v.contact_x[i], ryw = sh * v.contact_x[i];
+            const double px = s.x + rxw, py = s.y + ryw;
+            const double vax = s.vx - s.wz * ryw, vay = s.vy + s.wz * rxw;
+            for (int j = 0; j < 3; ++j) {
+                const double sxw = cb * v.contact_x[j], syw = sb * v.contact_x[j];
+                const double qx = b.x + sxw, qy = b.y + syw;
+                const double ex = px - qx, ey = py - qy;
+                const double d2 = ex * ex + ey * ey;
+                if (d2 >= r2 * r2 || d2 <= 0.0) continue;
+                const double d = sqrt(d2);
+                const double nxv = ex / d, nyv = ey / d;
+                const double vbx = b.vx - b.wz * syw, vby = b.vy + b.wz * sxw;
+                const double vn = (vax - vbx) * nxv + (vay - vby) * nyv;
+                const double mag = v.contact_stiffness * (r2 - d) - v.contact_damping * vn;
+                if (mag <= 0.0) continue;
+                const double fx = mag * nxv, fy = mag * nyv;
+                f.fx += fx; f.fy += fy; f.tz += rxw * fy - ryw * fx;
+            }
+        }
+    }
+}
+
+template <bool MULTI>
+__device__ __forceinline__ void integrate(const DeviceParams& P, CarCore& s, const PubPose* pub, int my_slot)
+{
+    const FtgpVehicle& v = P.veh;
+    const double dt = P.dt;
+    const double ch = 1.0 - 2.0 * (s.qz * s.qz), sh = 2.0 * (s.qw * s.qz);
+    // Ackermann coupling, mushr.em.xml:185-186
+    const double q = s.qs;
+    const double dfl = q * (1.0 + q * (0.375 + q * (0.140625 + q * -0.0722656)));
+    const double dfr = q * (1.0 + q * (-0.375 + q * (0.140625 + q * 0.0722656)));
+    const double cw[4] = { spec_cos(dfl), spec_cos(dfr), 1.0, 1.0 };
+    const double sw[4] = { spec_sin(dfl), spec_sin(dfr), 0.0, 0.0 };
+    // velocity servo on the tendon = mean wheel spin, mushr.em.xml:180,191-196
+    const double wbar = 0.25 * (((s.w[0] + s.w[1]) + s.w[2]) + s.w[3]);
+    double fa = v.throttle_kv * (s.u_speed - v.throttle_gear * wbar);
+    if (fa > v.throttle_force_limit) fa = v.throttle_force_limit;
+    if (fa < -v.throttle_force_limit) fa = -v.throttle_force_limit;
+    const double ta = (v.throttle_gear * 0.25) * fa;
+    Force f = { 0.0, 0.0, 0.0 };
+    double wn[4];
+    #pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const double rxw = ch * v.wheel_x[i] - sh * v.wheel_y[i];
+        const double ryw = sh * v.wheel_x[i] + ch * v.wheel_y[i];
+        const double vpx = s.vx - s.wz * ryw, vpy = s.vy + s.wz * rxw;
+        const double fdx = ch * cw[i] - sh * sw[i], fdy = sh * cw[i] + ch * sw[i];
+        const double vlong = (vpx * fdx + vpy * fdy) - v.wheel_radius * s.w[i];
+        const double vlat = vpy * fdx - vpx * fdy;
+        double flong = -(v.tire_damping * vlong), flat = -(v.tire_damping * vlat);
+        const double lim = v.friction * P.wheel_load[i];
+        const double m2 = flong * flong + flat * flat;
+        if (m2 > lim * lim) { const double sc = lim / sqrt(m2); flong = flong * sc; flat = flat * sc; }
+        const double fx = flong * fdx - flat * fdy, fy = flong * fdy + flat * fdx;
+        f.fx += fx; f.fy += fy; f.tz += rxw * fy - ryw * fx;
+        wn[i] = (v.wheel_inertia * s.w[i] + dt * (ta - v.wheel_radius * flong)) / (v.wheel_inertia + dt * v.wheel_damping);
+    }
+    wall_contact(P, s, ch, sh, f);
+    if (MULTI) car_contact(P, s, ch, sh, pub, my_slot, f);
+    const double nvx = s.vx + dt * (f.fx / v.mass);
+    const double nvy = s.vy + dt * (f.fy / v.mass);
+    const double nwz = s.wz + dt * (f.tz / v.izz);
+    // position servo on the steering joint, implicit damping (mushr.em.xml:78,179)
+    double nqsd = (v.steer_inertia * s.qsd + dt * (v.steer_kp * (s.u_steer - s.qs))) / (v.steer_inertia + dt * v.steer_damping);
+    double nqs = s.qs + dt * nqsd;
+    if (nqs > v.steer_limit) { nqs = v.steer_limit; if (nqsd > 0.0) nqsd = 0.0; }
+    if (nqs < -v.steer_limit) { nqs = -v.steer_limit; if (nqsd < 0.0) nqsd = 0.0; }
+    // semi-implicit Euler: positions with the new velocities
+    const double h = (0.5 * dt) * nwz;
+    const double chh = spec_cos(h), shh = spec_sin(h);
+    const double nw = s.qw * chh - s.qz * shh, nz = s.qz * chh + s.qw * shh;
+    const double n = sqrt(nw * nw + nz * nz);
+    s.x = s.x + dt * nvx;
+    s.y = s.y + dt * nvy;
+    s.qw = nw / n; s.qz = nz / n;
+    s.vx = nvx; s.vy = nvy; s.wz = nwz;
+    s.qs = nqs; s.qsd = nqsd;
+    #pragma unroll
+    for (int i = 0; i < 4; ++i) s.w[i] = wn[i];
+}
+
+// =============================================================================================
+// K5: on-device drivers.  nidc.py:12-131 / fast.py:11-139 restated for one wave; the previous scan sits in LDS.
+// =============================================================================================
+__device__ __forceinline__ void policy_disparity(const DeviceParams& P, float* __restrict__ scan, CarCore& s, bool fast)
+{
+    const int lane = lane_id();
+    const int n = P.n_rays;
+    const double car_width = fast ? 0.06 : 0.12;                    // fast.py:4 / nidc.py:5
+    const double rpp = (2 * M_PI) / (double)n;                      // nidc.py:121
+    const int eighth = (int)((double)n / 8.0);                      // nidc.py:18
+    const int m = n - 2 * eighth;
+    float* __restrict__ proc = scan + eighth;                       // nidc.py:19 (the copy is the LDS image itself)
+    const float range0 = scan[0];
+    // disparities on the UNMODIFIED scan (nidc.py:26-40): one ballot per 64 elements, parked in lane (pass)
+    uint64_t mymask = 0;
+    const int npass = (m + FTGP_WAVE - 1) / FTGP_WAVE;
+    for (int p = 0; p < npass; ++p) {
+        const int i = p * FTGP_WAVE + lane;
+        bool flag = false;
+        if (i >= 1 && i < m) flag = fabs((double)proc[i] - (double)proc[i - 1]) > 0.6;
+        const uint64_t b = __ballot(flag);
+        if (lane == (p & 63)) mymask = b;
+        if ((p & 63) == 63 || p == npass - 1) {
+            // flush this group of up to 64 ballots: extend the disparities in index order (nidc.py:86-105)
+            const int p0 = p & ~63;
+            const double width = (car_width / 2) * (1 + 300.0 / 100);  // nidc.py:93
+            for (int pp = p0; pp <= p; ++pp) {
+                uint32_t lo = __builtin_amdgcn_readlane((uint32_t)mymask, pp & 63);
+                uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(mymask >> 32), pp & 63);
+                uint64_t mask = ((uint64_t)hi << 32) | lo;
+                while (mask) {
+                    const int bit = __builtin_ctzll(mask);
+                    mask &= mask - 1;
+                    const int index = pp * FTGP_WAVE + bit;
+                    const int first = index - 1;
+                    wave_lds_sync();
+                    const float p0v = proc[first], p1v = proc[first + 1];
+                    const int close_idx = first + ((p1v < p0v) ? 1 : 0);   // argmin: first minimum
+                    const int far_idx = first + ((p1v > p0v) ? 1 : 0);     // argmax: first maximum
+                    const float ndf = (p1v < p0v) ? p1v : p0v;
+                    const double close_dist = (double)ndf;
+                    const double angle = 2 * atan(width / (2 * close_dist));   // nidc.py:57
+                    const double cnt = ceil(angle / rpp);
+                    const int num = (cnt > 2147483000.0) ? 2147483000 : (cnt < -2147483000.0 ? -2147483000 : (int)cnt);
+                    const bool cover_right = close_idx < far_idx;
+                    for (int i = lane; i < num; i += FTGP_WAVE) {          // nidc.py:72-83, one target per lane
+                        const int idx = cover_right ? close_idx + 1 + i : close_idx - 1 - i;
+                        if (idx < 0 || idx >= m) break;
+                        if (proc[idx] > ndf) proc[idx] = ndf;
+                    }
+                }
+            }
+            mymask = 0;
+        }
+    }
+    wave_lds_sync();
+    // argmax, first maximum (nidc.py:127)
+    float bv = -INFINITY; int bi = 0x7fffffff;
+    for (int i = lane; i < m; i += FTGP_WAVE) { const float x = proc[i]; if (bi == 0x7fffffff || x > bv) { bv = x; bi = i; } }
+    #pragma unroll
+    for (int mm = 32; mm >= 1; mm >>= 1) {
+        const float ov = __shfl_xor(bv, mm, FTGP_WAVE);
+        const int oi = __shfl_xor(bi, mm, FTGP_WAVE);
+        if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
+    }
+    double ang = ((double)bi - ((double)m / 2)) * rpp;              // nidc.py:112
+    const double lim = 90.0 * (M_PI / 180.0);
+    if (ang < -lim) ang = -lim;
+    if (ang > lim) ang = lim;
+    double speed;
+    if (!fast) {
+        speed = 0.5 * 5 * (1 - fabs(ang) / (1.57 * 2));             // nidc.py:130
+    } else {
+        const double old = 0.0;                                     // fast.py:131-133
+        ang = s.last_steer * old + ang * (1 - old);
+        s.last_steer = ang;
+        if (fabs(ang) < 0.1 && (double)range0 > 0.5) speed = 7.0;   // fast.py:135-138
+        else { const double sp = 0.5 * 5 * (1 - fabs(ang) / M_PI); speed = sp < 2.0 ? sp : 2.0; }
+    }
+    s.u_speed = speed; s.u_steer = ang;
+}
+
+__device__ __forceinline__ void policy_apply(const DeviceParams& P, int policy, float* scan, CarCore& s, int ci, int64_t steps)
+{
+    if (s.finished) { s.u_speed = 0.0; s.u_steer = 0.0; return; }  // finished cars get the null driver (custom.py:1446)
+    switch (policy) {
+    case FTGP_POLICY_LOBOTOMY: s.u_speed = 0.0; s.u_steer = 0.0; break;   // lobotomy.py:2-3
+    case FTGP_POLICY_NIDC: policy_disparity(P, scan, s, false); break;
+    case FTGP_POLICY_FAST: policy_disparity(P, scan, s, true); break;
+    case FTGP_POLICY_RANDOM: {
+        uint64_t h = splitmix64(P.seed + (uint64_t)ci * 0x9E3779B97F4A7C15ull);
+        h = splitmix64(h ^ (uint64_t)steps);
+        s.u_speed = 3.0 * u01(h);
+        s.u_steer = 2.0 * u01(splitmix64(h)) - 1.0;
+        break; }
+    default: break;
+    }
+}
+
+// =============================================================================================
+// The step kernel.  Per step and car, in the order of the reference loop (custom.py:1337-1426):
+//   driver(previous scan) -> ctrl -> [mj_step: sensors at the current pose, integrate] -> steps += 1 ->
+//   progress at the new pose (= the head of the next loop iteration).
+// =============================================================================================
+template <bool MULTI>
+__global__ void __launch_bounds__(MULTI ? 512 : 256, MULTI ? 2 : 4) ftgp_step_kernel(DeviceParams P, int policy, int n_steps, int cars_per_block)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ci = __builtin_amdgcn_readfirstlane((int)blockIdx.x * cars_per_block + wave);
+    const bool live = ci < P.n_cars;
+    const int env = live ? ci / P.cars_per_env : 0;
+    const int my_slot = MULTI ? wave : 0;   // MULTI: one env per block, wave == car slot
+    const bool need_scan = (policy == FTGP_POLICY_NIDC || policy == FTGP_POLICY_FAST);
+    const int scan_floats = (P.n_rays + 3) & ~3;
+    float* scan = need_scan ? reinterpret_cast<float*>(lds_raw) + wave * scan_floats : nullptr;
+    PubPose* pub = reinterpret_cast<PubPose*>(lds_raw + (need_scan ? (size_t)cars_per_block * scan_floats * sizeof(float) : 0));
+
+    CarCore s;
+    int64_t steps = 0;
+    float* my_ranges = nullptr;
+    if (live) {
+        s = static_cast<const CarCore&>(P.cars[ci]);
+        steps = P.steps[env];
+        my_ranges = P.ranges + (size_t)ci * P.ranges_stride;
+        if (need_scan) {
+            for (int j = lane; j < P.n_rays; j += FTGP_WAVE) scan[j] = my_ranges[j];
+        }
+    }
+    for (int it = 0; it < n_steps; ++it) {
+        if (live) {
+            if (policy != FTGP_POLICY_HOST) {
+                if (need_scan) wave_lds_sync();
+                policy_apply(P, policy, scan, s, ci, steps);
+            }
+        }
+        if (MULTI) {
+            if (live && lane == 0) {
+                PubPose pp; pp.x = s.x; pp.y = s.y; pp.qw = s.qw; pp.qz = s.qz; pp.vx = s.vx; pp.vy = s.vy; pp.wz = s.wz; pp.pad = 0.0;
+                pub[my_slot] = pp;
+            }
+            __syncthreads();
+        }
+        if (live) {
+            lidar_sweep<MULTI>(P, s, my_ranges, scan, pub, my_slot);   // sensors at the pre-integration pose
+            integrate<MULTI>(P, s, pub, my_slot);
+            steps += 1;
+            progress_wave(P, s, steps, P.cars[ci].times);
+        }
+        if (MULTI) __syncthreads();   // everybody has read pub before the next step overwrites it
+    }
+    if (live && lane == 0) {
+        static_cast<CarCore&>(P.cars[ci]) = s;
+        if (ci % P.cars_per_env == 0) P.steps[env] = steps;
+    }
+}
+
+// K5 alone: one wave per car evaluates the driver on the scan stored in P.ranges (ftgp_policy_eval).
+__global__ void __launch_bounds__(256) ftgp_policy_kernel(DeviceParams P, int policy, double* __restrict__ ctrl_out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ci = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + wave);
+    if (ci >= P.n_cars) return;
+    const int scan_floats = (P.n_rays + 3) & ~3;
+    float* scan = reinterpret_cast<float*>(lds_raw) + wave * scan_floats;
+    const float* my_ranges = P.ranges + (size_t)ci * P.ranges_stride;
+    for (int j = lane; j < P.n_rays; j += FTGP_WAVE) scan[j] = my_ranges[j];
+    wave_lds_sync();
+    CarCore s = static_cast<const CarCore&>(P.cars[ci]);
+    policy_apply(P, policy, scan, s, ci, P.steps[ci / P.cars_per_env]);
+    if (lane == 0) {
+        P.cars[ci].u_speed = s.u_speed; P.cars[ci].u_steer = s.u_steer; P.cars[ci].last_steer = s.last_steer;
+        if (ctrl_out) { ctrl_out[2 * ci] = s.u_speed; ctrl_out[2 * ci + 1] = s.u_steer; }
+    }
+}
+
+template __global__ void ftgp_step_kernel<false>(DeviceParams, int, int, int);
+template __global__ void ftgp_step_kernel<true>(DeviceParams, int, int, int);
+
+// =============================================================================================
+// K4: reset / spawn (custom.py:1089-1128, 1232-1245, 81-87), one car per lane; then K3 at the spawn pose.
+// =============================================================================================
+__device__ __forceinline__ void progress_lane(const DeviceParams& P, CarCore& s, int64_t steps, double* __restrict__ times)
+{
+    double best = 0.0; int closest = 0;
+    for (int i = 0; i < FTGP_PATH_POINTS; ++i) {
+        const double dx = P.path[2 * i] - s.x, dy = P.path[2 * i + 1] - s.y;
+        const double d = dx * dx + dy * dy;
+        if (i == 0 || d < best) { best = d; closest = i; }
+    }
+    progress_update(P, s, steps, closest, best, times);
+}
+
+__global__ void ftgp_reset_kernel(DeviceParams P, const uint8_t* __restrict__ env_mask)
+{
+    const int ci = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ci >= P.n_cars) return;
+    const int env = ci / P.cars_per_env, car = ci % P.cars_per_env;
+    if (env_mask && !env_mask[env]) return;
+    CarCore s;
+    memset(&s, 0, sizeof s);
+    const int p = (P.spawn_mode == 0) ? (car + 5) * 2 : (10 + 7 * env + 2 * car) % 98;   // custom.py:1112
+    s.offset = p;
+    s.good_start = 1;
+    s.x = P.spawn[4 * p]; s.y = P.spawn[4 * p + 1];
+    double qw = P.spawn[4 * p + 2], qz = P.spawn[4 * p + 3];
+    if (P.spawn_mode == 1) {
+        const uint64_t h = splitmix64(P.seed ^ (0xA0761D6478BD642Full + (uint64_t)ci));
+        const double j = 0.2 * u01(h) - 0.1;
+        const double cj = spec_cos(0.5 * j), sj = spec_sin(0.5 * j);
+        const double nw = qw * cj - qz * sj, nz = qz * cj + qw * sj;
+        const double n = sqrt(nw * nw + nz * nz);
+        qw = nw / n; qz = nz / n;
+    }
+    s.qw = qw; s.qz = qz;
+    if (car == 0) P.steps[env] = 0;
+    for (int k = 0; k < FTGP_MAX_LAP_TIMES; ++k) P.cars[ci].times[k] = 0.0;
+    progress_lane(P, s, 0, P.cars[ci].times);
+    static_cast<CarCore&>(P.cars[ci]) = s;
+    float* r = P.ranges + (size_t)ci * P.ranges_stride;
+    for (int j = 0; j < P.n_rays; ++j) r[j] = 0.0f;    // sensordata = 0 after mj_resetData (custom.py:1092)
+}
+
+__global__ void ftgp_progress_kernel(DeviceParams P)
+{
+    const int ci = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ci >= P.n_cars) return;
+    CarCore s = static_cast<const CarCore&>(P.cars[ci]);
+    progress_lane(P, s, P.steps[ci / P.cars_per_env], P.cars[ci].times);
+    static_cast<CarCore&>(P.cars[ci]) = s;
+}
+
+__global__ void ftgp_set_ctrl_kernel(DeviceParams P, const double* __restrict__ ctrl, const uint8_t* __restrict__ mask)
+{
+    const int ci = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ci >= P.n_cars) return;
+    if (mask && !mask[ci]) return;
+    P.cars[ci].u_speed = ctrl[2 * ci];
+    P.cars[ci].u_steer = ctrl[2 * ci + 1];
+}
+
+__global__ void ftgp_set_pose_kernel(DeviceParams P, const double* __restrict__ pose)
+{
+    const int ci = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ci >= P.n_cars) return;
+    const double* o = pose + (size_t)ci * FTGP_POSE_DOUBLES;
+    const double n = sqrt(o[3] * o[3] + o[6] * o[6]);
+    CarState& s = P.cars[ci];
+    s.x = o[0]; s.y = o[1]; s.qw = o[3] / n; s.qz = o[6] / n; s.vx = o[7]; s.vy = o[8]; s.wz = o[12];
+}
+
+// Metrics record (FTGP_METRIC_DOUBLES): one block, deterministic tree reduction (integers are exact in f64).
+__global__ void __launch_bounds__(256) ftgp_metrics_kernel(DeviceParams P, double* __restrict__ out)
+{
+    __shared__ double red[6][256];
+    double steps = 0, laps = 0, absc = 0, fin = 0, off = 0, tmin = INFINITY, tmax = -INFINITY;
+    for (int e = threadIdx.x; e < P.n_envs; e += blockDim.x) steps += (double)P.steps[e];
+    for (int i = threadIdx.x; i < P.n_cars; i += blockDim.x) {
+        const CarState& a = P.cars[i];
+        const int lc = a.good_start ? a.completion : -(100 - a.completion);     // custom.py:132-143
+        laps += a.laps; absc += a.laps * 100 + lc; fin += a.finished; off += a.off_track;
+        const int n = a.n_times < FTGP_MAX_LAP_TIMES ? a.n_times : FTGP_MAX_LAP_TIMES;
+        for (int k = 0; k < n; ++k) { tmin = fmin(tmin, a.times[k]); tmax = fmax(tmax, a.times[k]); }
+    }
+    __shared__ double rmin[256], rmax[256];
+    red[0][threadIdx.x] = steps; red[1][threadIdx.x] = laps; red[2][threadIdx.x] = absc;
+    red[3][threadIdx.x] = fin; red[4][threadIdx.x] = off; rmin[threadIdx.x] = tmin; rmax[threadIdx.x] = tmax;
+    __syncthreads();
+    for (int w = 128; w >= 1; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            for (int q = 0; q < 5; ++q) red[q][threadIdx.x] += red[q][threadIdx.x + w];
+            rmin[threadIdx.x] = fmin(rmin[threadIdx.x], rmin[threadIdx.x + w]);
+            rmax[threadIdx.x] = fmax(rmax[threadIdx.x], rmax[threadIdx.x + w]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out[0] = red[0][0]; out[1] = (double)P.n_cars; out[2] = red[1][0]; out[3] = red[2][0];
+        out[4] = red[3][0]; out[5] = red[4][0]; out[6] = rmin[0]; out[7] = rmax[0];
+    }
+}

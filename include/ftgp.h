@@ -184,6 +184,11 @@ int ftgp_get_steps(FtgpEnv *env, int64_t *out);
 /* Overwrite poses (testing / curriculum): double[n_cars][FTGP_POSE_DOUBLES]; only x, y, yaw (from qw, qz), vx, vy, wz are used. */
 int ftgp_set_pose(FtgpEnv *env, const double *pose);
 
+/* Evaluate a device policy once on caller-supplied scans: ranges float[n_cars][n_rays] replaces the stored scan,
+ * the policy writes each car's controls (and fast.py's last_steering_angle); ctrl_out double[n_cars][2] (may be NULL).
+ * Replaces one vehicle_state.driver.process_lidar(ranges) call per car (custom.py:1404). */
+int ftgp_policy_eval(FtgpEnv *env, int policy, const float *ranges, double *ctrl_out);
+
 /* Re-evaluate the lap-progress block (custom.py:1340-1372) at the current poses and step counts, without integrating.
  * ftgp_reset ends with this; use it after ftgp_set_pose. */
 int ftgp_eval_progress(FtgpEnv *env);

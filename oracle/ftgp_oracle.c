@@ -606,7 +606,7 @@ static void policy_car(OracleEnv *e, int policy, int ci)
 }
 
 /* standalone driver evaluation for the G1 golden vectors: ranges float[n], state = last_steering_angle in/out */
-int oracle_policy_eval(int policy, int n_rays, const float *ranges, double *last_steer, double *speed, double *steer)
+int oracle_policy_eval1(int policy, int n_rays, const float *ranges, double *last_steer, double *speed, double *steer)
 {
     OracleEnv tmp; memset(&tmp, 0, sizeof tmp); tmp.cfg.n_rays = n_rays;
     Car c; memset(&c, 0, sizeof c); c.last_steer = *last_steer;
@@ -829,6 +829,16 @@ int oracle_get_ctrl(OracleEnv *e, double *out)
     return 0;
 }
 int oracle_get_steps(OracleEnv *e, int64_t *out) { memcpy(out, e->steps, sizeof(int64_t) * (size_t)e->cfg.n_envs); return 0; }
+int oracle_policy_eval(OracleEnv *e, int policy, const float *ranges, double *ctrl_out)
+{
+    if (policy < FTGP_POLICY_LOBOTOMY || policy > FTGP_POLICY_RANDOM) return fail(FTGP_ERR_ARG, "policy_eval: device policies only");
+    memcpy(e->ranges, ranges, sizeof(float) * (size_t)e->n_cars * e->cfg.n_rays);
+    for (int i = 0; i < e->n_cars; ++i) {
+        policy_car(e, policy, i);
+        if (ctrl_out) { ctrl_out[2 * i] = e->cars[i].u_speed; ctrl_out[2 * i + 1] = e->cars[i].u_steer; }
+    }
+    return 0;
+}
 int oracle_eval_progress(OracleEnv *e) { for (int i = 0; i < e->n_cars; ++i) progress_car(e, i); return 0; }
 int oracle_get_field(OracleEnv *e, uint8_t *out) { memcpy(out, e->field, (size_t)e->cfg.track.width * e->cfg.track.height); return 0; }
 

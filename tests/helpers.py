@@ -18,8 +18,8 @@ def load_oracle():
     lib = CLib(ORACLE_SO, "oracle_")
     import ctypes as C
     d = lib.dll
-    d.oracle_policy_eval.restype = C.c_int
-    d.oracle_policy_eval.argtypes = [C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    d.oracle_policy_eval1.restype = C.c_int
+    d.oracle_policy_eval1.argtypes = [C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     d.oracle_fakelidar.restype = C.c_int
     d.oracle_fakelidar.argtypes = [C.c_double, C.c_double, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                    C.c_double, C.c_void_p, C.c_void_p]
@@ -40,6 +40,6 @@ def oracle_policy(lib, policy, scan_f32, last_steer=0.0):
     import ctypes as C
     s = np.ascontiguousarray(scan_f32, dtype=np.float32)
     ls, sp, st = C.c_double(last_steer), C.c_double(), C.c_double()
-    rc = lib.dll.oracle_policy_eval(policy, s.size, s.ctypes.data, C.byref(ls), C.byref(sp), C.byref(st))
+    rc = lib.dll.oracle_policy_eval1(policy, s.size, s.ctypes.data, C.byref(ls), C.byref(sp), C.byref(st))
     assert rc == 0
     return sp.value, st.value, ls.value

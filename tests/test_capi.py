@@ -1,0 +1,60 @@
+"""CPU-side checks of the boundary: the HIP library loads, exports every symbol include/ftgp.h declares,
+and refuses loudly to run without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from ft_grandprix_amd import capi
+from ft_grandprix_amd.track import load_track
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "ftgp.h")).read()
+    return sorted(set(re.findall(r"\b(ftgp_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    assert header_symbols() == sorted("ftgp_" + s for s in capi.API_SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol(product):
+    for sym in header_symbols():
+        assert hasattr(product.dll, sym), sym
+
+
+def test_struct_layouts_match_the_header(product, oracle):
+    # both libraries fill FtgpVehicle through the same C struct: identical bytes => identical layout and constants
+    a, b = product.default_vehicle(), oracle.default_vehicle()
+    assert bytes(a) == bytes(b)
+    assert C.sizeof(capi.FtgpVehicle) == 8 * 37
+    assert a.mass == pytest.approx(5.632768) and a.wheel_x[0] == 0.06925 and a.lidar_x == -0.0525
+
+
+def test_no_gpu_means_loud_failure_not_fallback(product):
+    if product.fn("device_count")() >= 1:
+        pytest.skip("a GPU is present")
+    with pytest.raises(capi.FtgpError) as ei:
+        capi.Env(product, load_track("small-circle"), n_envs=1, n_rays=8)
+    assert ei.value.code == -2 and "no CPU fallback" in str(ei.value)
+
+
+def test_bad_arguments_are_rejected(oracle):
+    t = load_track("small-circle")
+    with pytest.raises(capi.FtgpError):
+        capi.Env(oracle, t, n_envs=0)
+    with pytest.raises(capi.FtgpError):
+        capi.Env(oracle, t, n_envs=1, cars_per_env=9)
+
+
+def test_product_package_never_references_the_oracle():
+    pkg = os.path.join(ROOT, "ft_grandprix_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "libftgp_oracle" not in text and "oracle/" not in text.replace("the oracle/", ""), f
