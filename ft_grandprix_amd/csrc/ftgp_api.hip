@@ -71,8 +71,8 @@ struct FtgpEnv {
     hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_metrics = nullptr;
     bool timed = false;
     // device buffers
-    uint32_t* d_bits = nullptr; uint8_t* d_field = nullptr; double* d_path = nullptr; double* d_spawn = nullptr;
-    float* d_ray_bx = nullptr; float* d_ray_by = nullptr;
+    uint8_t* d_coarse = nullptr; uint2* d_rank = nullptr; uint8_t* d_fine = nullptr;
+    double* d_path = nullptr; double* d_spawn = nullptr; float* d_ray = nullptr; void* d_veh = nullptr;
     CarState* d_cars = nullptr; float* d_ranges = nullptr; int64_t* d_steps = nullptr;
     uint8_t* d_env_mask = nullptr; uint8_t* d_car_mask = nullptr; double* d_ctrl = nullptr; double* d_pose = nullptr;
     double* d_metrics = nullptr; double* d_gather = nullptr;
@@ -85,30 +85,96 @@ struct FtgpEnv {
 
 namespace {
 
-// exact chessboard distance transform (two raster sweeps over a padded int16 image), clamped to 255
-void build_field(const FtgpTrack& t, std::vector<uint8_t>& out)
+// exact chessboard distance transform of a W x H occupancy image (two raster sweeps over a padded image)
+void chessboard_dt(const std::vector<uint8_t>& occ, int W, int H, std::vector<int>& out)
 {
-    const int W = t.width, H = t.height, S = W + 2;
-    std::vector<int16_t> d((size_t)S * (H + 2), (int16_t)30000);
-    auto at = [&](int x, int y) -> int16_t& { return d[(size_t)(y + 1) * S + (x + 1)]; };
+    const int S = W + 2;
+    std::vector<int> d((size_t)S * (H + 2), 1 << 20);
+    auto at = [&](int x, int y) -> int& { return d[(size_t)(y + 1) * S + (x + 1)]; };
     for (int y = 0; y < H; ++y)
-        for (int x = 0; x < W; ++x)
-            if ((t.bits[(size_t)y * t.words_per_row + (x >> 5)] >> (x & 31)) & 1u) at(x, y) = 0;
+        for (int x = 0; x < W; ++x) if (occ[(size_t)y * W + x]) at(x, y) = 0;
     for (int y = 0; y < H; ++y)
         for (int x = 0; x < W; ++x) {
-            int v = at(x, y);
-            int n = std::min(std::min((int)at(x - 1, y), (int)at(x - 1, y - 1)), std::min((int)at(x, y - 1), (int)at(x + 1, y - 1))) + 1;
-            if (n < v) at(x, y) = (int16_t)n;
+            const int n = std::min(std::min(at(x - 1, y), at(x - 1, y - 1)), std::min(at(x, y - 1), at(x + 1, y - 1))) + 1;
+            if (n < at(x, y)) at(x, y) = n;
         }
     for (int y = H - 1; y >= 0; --y)
         for (int x = W - 1; x >= 0; --x) {
-            int v = at(x, y);
-            int n = std::min(std::min((int)at(x + 1, y), (int)at(x + 1, y + 1)), std::min((int)at(x, y + 1), (int)at(x - 1, y + 1))) + 1;
-            if (n < v) at(x, y) = (int16_t)n;
+            const int n = std::min(std::min(at(x + 1, y), at(x + 1, y + 1)), std::min(at(x, y + 1), at(x - 1, y + 1))) + 1;
+            if (n < at(x, y)) at(x, y) = n;
         }
     out.resize((size_t)W * H);
     for (int y = 0; y < H; ++y)
-        for (int x = 0; x < W; ++x) out[(size_t)y * W + x] = (uint8_t)std::min(255, (int)at(x, y));
+        for (int x = 0; x < W; ++x) out[(size_t)y * W + x] = at(x, y);
+}
+
+// Two-level wall grid over 8x8-pixel blocks:
+//   fine   : for every non-empty block (row-major block order) 64 nibbles = chessboard distance in pixels from each
+//            of its pixels to the nearest wall pixel anywhere (0 = wall; at most 7 because the block holds a wall)
+//   rank   : per 32 blocks {non-empty bits, number of non-empty blocks before the word} -> index into fine
+//   coarse : one nibble per block = chessboard distance in blocks to the nearest non-empty block, clamped to 15
+struct HostGrid {
+    int nbx = 0, nby = 0, nwpr = 0, n_fine = 0;
+    std::vector<uint8_t> coarse;
+    std::vector<uint2> rank;
+    std::vector<uint8_t> fine;
+};
+
+void build_grid(const FtgpTrack& t, HostGrid& g)
+{
+    const int W = t.width, H = t.height;
+    g.nbx = (W + 7) >> 3; g.nby = (H + 7) >> 3; g.nwpr = (g.nbx + 31) >> 5;
+    std::vector<uint8_t> wall((size_t)W * H, 0), nonempty((size_t)g.nbx * g.nby, 0);
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x)
+            if ((t.bits[(size_t)y * t.words_per_row + (x >> 5)] >> (x & 31)) & 1u) {
+                wall[(size_t)y * W + x] = 1; nonempty[(size_t)(y >> 3) * g.nbx + (x >> 3)] = 1;
+            }
+    std::vector<int> dpx, dblk;
+    chessboard_dt(wall, W, H, dpx);
+    chessboard_dt(nonempty, g.nbx, g.nby, dblk);
+    g.rank.assign((size_t)g.nby * g.nwpr, make_uint2(0u, 0u));
+    g.fine.clear(); g.n_fine = 0;
+    for (int by = 0; by < g.nby; ++by)
+        for (int w = 0; w < g.nwpr; ++w) {
+            uint2 r = make_uint2(0u, (unsigned)g.n_fine);
+            for (int k = 0; k < 32; ++k) {
+                const int bx = w * 32 + k;
+                if (bx >= g.nbx || !nonempty[(size_t)by * g.nbx + bx]) continue;
+                r.x |= 1u << k;
+                uint8_t img[32] = { 0 };
+                for (int n = 0; n < 64; ++n) {
+                    const int x = bx * 8 + (n & 7), y = by * 8 + (n >> 3);
+                    // pixels beyond the image edge are never queried (the march leaves the image first); mark them distance 1
+                    const int dv = (x < W && y < H) ? std::min(15, dpx[(size_t)y * W + x]) : 1;
+                    img[n >> 1] |= (uint8_t)(dv << ((n & 1) << 2));
+                }
+                g.fine.insert(g.fine.end(), img, img + 32);
+                g.n_fine += 1;
+            }
+            g.rank[(size_t)by * g.nwpr + w] = r;
+        }
+    g.coarse.assign(((size_t)g.nbx * g.nby + 1) / 2, 0);
+    for (int q = 0; q < g.nbx * g.nby; ++q)
+        g.coarse[(size_t)q >> 1] |= (uint8_t)(std::min(15, dblk[(size_t)q]) << ((q & 1) << 2));
+}
+
+inline int pad16(size_t n) { return (int)((n + 15) & ~(size_t)15); }
+
+// LDS layout for `cpb` cars per workgroup; returns the total
+int lds_layout(DeviceParams& P, int cpb)
+{
+    int o = 0;
+    P.off_veh = o;    o += pad16(sizeof(VehLds));
+    P.off_fine = o;   o += std::max(16, pad16((size_t)P.n_fine * 32));
+    P.off_rank = o;   o += pad16((size_t)P.nby * P.nwpr * 8);
+    P.off_path = o;   o += pad16(sizeof(double) * 2 * FTGP_PATH_POINTS);
+    P.off_coarse = o; o += pad16(((size_t)P.nbx * P.nby + 1) / 2);
+    P.off_ray = o;    o += 2 * P.ray_floats * (int)sizeof(float);
+    P.off_state = o;  o += cpb * (int)sizeof(CarCore);
+    P.off_scan = o;   o += cpb * P.scan_floats * (int)sizeof(float);
+    P.lds_bytes = o;
+    return o;
 }
 
 int sync_cars_to_host(FtgpEnv* e)
@@ -128,19 +194,12 @@ int launch_steps(FtgpEnv* e, int policy, int n_steps)
     HIP_TRY(hipSetDevice(e->device));
     const int cpb = e->cars_per_block;
     const int blocks = (e->P.n_cars + cpb - 1) / cpb;
-    const bool need_scan = (policy == FTGP_POLICY_NIDC || policy == FTGP_POLICY_FAST);
-    const size_t scan_floats = (size_t)((e->P.n_rays + 3) & ~3);
-    size_t lds = (need_scan ? (size_t)cpb * scan_floats * sizeof(float) : 0) + (e->multi ? (size_t)cpb * sizeof(PubPose) : 0);
-    if (lds > 160 * 1024) return fail(FTGP_ERR_ARG, "scan does not fit LDS%s");
     HIP_TRY(hipEventRecord(e->ev_start, e->stream));
     if (n_steps > 0) {
-        if (e->multi) {
-            if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)ftgp_step_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(ftgp_step_kernel<true>, dim3(blocks), dim3(cpb * FTGP_WAVE), lds, e->stream, e->P, policy, n_steps, cpb);
-        } else {
-            if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)ftgp_step_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(ftgp_step_kernel<false>, dim3(blocks), dim3(cpb * FTGP_WAVE), lds, e->stream, e->P, policy, n_steps, cpb);
-        }
+        if (e->multi)
+            hipLaunchKernelGGL(ftgp_step_kernel<true>, dim3(blocks), dim3(cpb * FTGP_WAVE), (size_t)e->P.lds_bytes, e->stream, e->P, policy, n_steps, cpb);
+        else
+            hipLaunchKernelGGL(ftgp_step_kernel<false>, dim3(blocks), dim3(cpb * FTGP_WAVE), (size_t)e->P.lds_bytes, e->stream, e->P, policy, n_steps, cpb);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(e->ev_stop, e->stream));
@@ -198,7 +257,7 @@ int ftgp_destroy(FtgpEnv* e)
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->side) (void)hipStreamSynchronize(e->side);
     if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
-    void* bufs[] = { e->d_bits, e->d_field, e->d_path, e->d_spawn, e->d_ray_bx, e->d_ray_by, e->d_cars, e->d_ranges,
+    void* bufs[] = { e->d_veh, e->d_coarse, e->d_rank, e->d_fine, e->d_path, e->d_spawn, e->d_ray, e->d_cars, e->d_ranges,
                      e->d_steps, e->d_env_mask, e->d_car_mask, e->d_ctrl, e->d_pose, e->d_metrics, e->d_gather };
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (e->ev_start) (void)hipEventDestroy(e->ev_start);
@@ -265,19 +324,22 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
         P.wheel_load[2] = P.wheel_load[3] = 0.5 * (wtot * (a_f / (a_f + a_r)));
     }
     e->multi = cfg->cars_per_env > 1;
-    e->cars_per_block = e->multi ? cfg->cars_per_env : 4;
-    if (!e->multi) {
-        if (const char* s = getenv("FTGP_CARS_PER_BLOCK")) { int c = atoi(s); if (c >= 1 && c <= 8) e->cars_per_block = c; }
-    }
 
     // host-side tables
-    std::vector<uint8_t> field;
-    build_field(t, field);
-    std::vector<float> bx(cfg->n_rays), by(cfg->n_rays);
+    HostGrid grid;
+    build_grid(t, grid);
+    P.nbx = grid.nbx; P.nby = grid.nby; P.nwpr = grid.nwpr; P.n_fine = grid.n_fine;
+    P.eighth = (int)((double)cfg->n_rays / 8.0);                    // nidc.py:18
+    P.scan_floats = (1 + (cfg->n_rays - 2 * P.eighth) + 3) & ~3;
+    P.ray_floats = (cfg->n_rays + 3) & ~3;
+    P.snap_eps = 1.0f / 512.0f;
+    if (t.width > 8192 || t.height > 8192) { snprintf(g_err, sizeof g_err, "images above 8192 pixels are not supported"); ftgp_destroy(e); return FTGP_ERR_ARG; }
+    const int scan_floats = P.ray_floats;
+    std::vector<float> ray(2 * (size_t)scan_floats, 0.0f);
     for (int j = 0; j < cfg->n_rays; ++j) {
         // mushr.em.xml:112-117: phi_j = radians(360/R*j - 90); the ray (+z of the site) is (sin phi, -cos phi, 0)
         const double phi = ((360.0 / (double)cfg->n_rays) * (double)j - 90.0) * (M_PI / 180.0);
-        bx[j] = (float)sin(phi); by[j] = (float)(-cos(phi));
+        ray[(size_t)j] = (float)sin(phi); ray[(size_t)scan_floats + j] = (float)(-cos(phi));
     }
     std::vector<double> spawn(4 * FTGP_PATH_POINTS);
     for (int p = 0; p < FTGP_PATH_POINTS; ++p) {
@@ -288,13 +350,42 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
         spawn[4 * p + 2] = cos(ang / 2); spawn[4 * p + 3] = sin(ang / 2);
     }
 
-    const size_t nbits = (size_t)t.height * t.words_per_row;
-    CREATE_TRY(hipMalloc(&e->d_bits, nbits * 4));
-    CREATE_TRY(hipMalloc(&e->d_field, field.size()));
-    CREATE_TRY(hipMalloc(&e->d_path, sizeof(double) * 2 * FTGP_PATH_POINTS));
+    // cars (waves) per workgroup: as many as fit the 160 KiB of LDS next to the track, at most 16 (one workgroup per CU)
+    {
+        const int unit = e->multi ? cfg->cars_per_env : 1;
+        int want = 16;
+        if (const char* sv = getenv("FTGP_CARS_PER_BLOCK")) { const int c = atoi(sv); if (c >= 1 && c <= 16) want = c; }
+        int cpb = (want / unit) * unit;
+        while (cpb >= unit && lds_layout(P, cpb) > 160 * 1024) cpb -= unit;
+        if (cpb < unit) {
+            snprintf(g_err, sizeof g_err, "track grid (%d non-empty 8x8 blocks of %dx%d) + %d-ray scan do not fit the 160 KiB LDS",
+                     P.n_fine, P.nbx, P.nby, P.n_rays);
+            ftgp_destroy(e);
+            return FTGP_ERR_ARG;
+        }
+        e->cars_per_block = cpb;
+        lds_layout(P, cpb);
+    }
+    CREATE_TRY(hipFuncSetAttribute((const void*)ftgp_step_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CREATE_TRY(hipFuncSetAttribute((const void*)ftgp_step_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+
+    const size_t sz_fine = (size_t)(P.off_rank - P.off_fine), sz_rank = (size_t)(P.off_path - P.off_rank);
+    const size_t sz_path = (size_t)(P.off_coarse - P.off_path), sz_coarse = (size_t)(P.off_ray - P.off_coarse);
+    const size_t sz_ray = (size_t)(P.off_state - P.off_ray);
+    {
+        std::vector<unsigned char> vimg((size_t)pad16(sizeof(VehLds)), 0);
+        VehLds vl; vl.v = P.veh; for (int i = 0; i < 4; ++i) vl.wheel_load[i] = P.wheel_load[i];
+        memcpy(vimg.data(), &vl, sizeof vl);
+        CREATE_TRY(hipMalloc(&e->d_veh, vimg.size()));
+        CREATE_TRY(hipMemcpy(e->d_veh, vimg.data(), vimg.size(), hipMemcpyHostToDevice));
+        P.veh_dev = e->d_veh;
+    }
+    CREATE_TRY(hipMalloc(&e->d_fine, sz_fine));
+    CREATE_TRY(hipMalloc(&e->d_rank, sz_rank));
+    CREATE_TRY(hipMalloc(&e->d_path, sz_path));
+    CREATE_TRY(hipMalloc(&e->d_coarse, sz_coarse));
+    CREATE_TRY(hipMalloc(&e->d_ray, sz_ray));
     CREATE_TRY(hipMalloc(&e->d_spawn, sizeof(double) * 4 * FTGP_PATH_POINTS));
-    CREATE_TRY(hipMalloc(&e->d_ray_bx, sizeof(float) * cfg->n_rays));
-    CREATE_TRY(hipMalloc(&e->d_ray_by, sizeof(float) * cfg->n_rays));
     CREATE_TRY(hipMalloc(&e->d_cars, sizeof(CarState) * (size_t)P.n_cars));
     CREATE_TRY(hipMalloc(&e->d_ranges, sizeof(float) * (size_t)P.n_cars * P.ranges_stride));
     CREATE_TRY(hipMalloc(&e->d_steps, sizeof(int64_t) * (size_t)P.n_envs));
@@ -303,16 +394,19 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
     CREATE_TRY(hipMalloc(&e->d_ctrl, sizeof(double) * 2 * (size_t)P.n_cars));
     CREATE_TRY(hipMalloc(&e->d_pose, sizeof(double) * FTGP_POSE_DOUBLES * (size_t)P.n_cars));
     CREATE_TRY(hipMalloc(&e->d_metrics, sizeof(double) * FTGP_METRIC_DOUBLES));
-    CREATE_TRY(hipMemcpy(e->d_bits, t.bits, nbits * 4, hipMemcpyHostToDevice));
-    CREATE_TRY(hipMemcpy(e->d_field, field.data(), field.size(), hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemset(e->d_fine, 0, sz_fine));
+    CREATE_TRY(hipMemset(e->d_rank, 0, sz_rank));
+    CREATE_TRY(hipMemset(e->d_coarse, 0, sz_coarse));
+    if (!grid.fine.empty()) CREATE_TRY(hipMemcpy(e->d_fine, grid.fine.data(), grid.fine.size(), hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemcpy(e->d_rank, grid.rank.data(), grid.rank.size() * sizeof(uint2), hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemcpy(e->d_coarse, grid.coarse.data(), grid.coarse.size(), hipMemcpyHostToDevice));
     CREATE_TRY(hipMemcpy(e->d_path, t.path, sizeof(double) * 2 * FTGP_PATH_POINTS, hipMemcpyHostToDevice));
     CREATE_TRY(hipMemcpy(e->d_spawn, spawn.data(), sizeof(double) * spawn.size(), hipMemcpyHostToDevice));
-    CREATE_TRY(hipMemcpy(e->d_ray_bx, bx.data(), sizeof(float) * bx.size(), hipMemcpyHostToDevice));
-    CREATE_TRY(hipMemcpy(e->d_ray_by, by.data(), sizeof(float) * by.size(), hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemcpy(e->d_ray, ray.data(), sizeof(float) * ray.size(), hipMemcpyHostToDevice));
     CREATE_TRY(hipMemset(e->d_ranges, 0, sizeof(float) * (size_t)P.n_cars * P.ranges_stride));
     CREATE_TRY(hipMemset(e->d_steps, 0, sizeof(int64_t) * (size_t)P.n_envs));
-    P.bits = e->d_bits; P.field = e->d_field; P.path = e->d_path; P.spawn = e->d_spawn;
-    P.ray_bx = e->d_ray_bx; P.ray_by = e->d_ray_by; P.cars = e->d_cars; P.ranges = e->d_ranges; P.steps = e->d_steps;
+    P.coarse = e->d_coarse; P.rank = e->d_rank; P.fine = e->d_fine; P.path = e->d_path; P.spawn = e->d_spawn;
+    P.ray_bx = e->d_ray; P.ray_by = e->d_ray + scan_floats; P.cars = e->d_cars; P.ranges = e->d_ranges; P.steps = e->d_steps;
 #undef CREATE_TRY
     int rc = ftgp_reset(e, nullptr);
     if (rc != 0) { ftgp_destroy(e); return rc; }
@@ -330,6 +424,8 @@ int ftgp_reset(FtgpEnv* e, const uint8_t* mask)
         dmask = e->d_env_mask;
     }
     hipLaunchKernelGGL(ftgp_reset_kernel, dim3((e->P.n_cars + 63) / 64), dim3(64), 0, e->stream, e->P, dmask);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(ftgp_zero_ranges_kernel, dim3(e->P.n_cars), dim3(256), 0, e->stream, e->P, dmask);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(e->stream));
     return 0;
@@ -433,7 +529,7 @@ int ftgp_policy_eval(FtgpEnv* e, int policy, const float* ranges, double* ctrl_o
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipMemcpy2DAsync(e->d_ranges, sizeof(float) * (size_t)e->P.ranges_stride, ranges, sizeof(float) * (size_t)e->P.n_rays,
                              sizeof(float) * (size_t)e->P.n_rays, (size_t)e->P.n_cars, hipMemcpyHostToDevice, e->stream));
-    const size_t lds = 4 * (size_t)((e->P.n_rays + 3) & ~3) * sizeof(float);
+    const size_t lds = 4 * ((size_t)e->P.scan_floats * sizeof(float) + sizeof(CarCore));
     if (lds > 64 * 1024) return fail(FTGP_ERR_ARG, "scan does not fit LDS%s");
     hipLaunchKernelGGL(ftgp_policy_kernel, dim3((e->P.n_cars + 3) / 4), dim3(256), lds, e->stream, e->P, policy, ctrl_out ? e->d_ctrl : nullptr);
     HIP_TRY(hipGetLastError());

@@ -37,8 +37,16 @@ struct DeviceParams {
     int32_t width, height, words_per_row, pad1;
     double px_size_x, px_size_y, origin_x, origin_y, inv_px_x, inv_px_y;
     float inv_px_x_f, inv_px_y_f;
-    const uint32_t* bits;         // wall bitmap
-    const uint8_t* field;         // chessboard distance to the nearest wall cell (0 on walls, <= 255)
+    // two-level wall grid over 8x8-pixel blocks (built on the host at create; staged into LDS by the step kernel)
+    int32_t nbx, nby, nwpr, n_fine;    // blocks per row / column, 32-block words per row, non-empty blocks
+    const uint8_t* coarse;        // 4 bits per block: chessboard distance in BLOCKS to the nearest non-empty block (0 = has walls), clamp 15
+    const uint2* rank;            // [nby][nwpr] {non-empty bits of 32 blocks, number of non-empty blocks before this word}
+    const uint8_t* fine;          // [n_fine][32] 4 bits per pixel of each non-empty block: chessboard distance in PIXELS to the nearest wall pixel
+    // LDS layout of the step kernel (byte offsets, all 16-B aligned)
+    int32_t off_veh, off_fine, off_rank, off_path, off_coarse, off_ray, off_state, off_scan, lds_bytes;
+    int32_t eighth, scan_floats, ray_floats;   // int(n_rays / 8); floats per LDS scan = 1 + (n_rays - 2*eighth) padded to 4; padded ray table
+    float snap_eps, pad3;         // the march re-checks a landing point with the exact comparisons within this distance of a pixel boundary
+    const void* veh_dev;          // VehLds image (vehicle constants + wheel loads) in HBM
     const double* path;           // [100][2]
     const double* spawn;          // [100][4] x, y, qw, qz
     const float* ray_bx;          // body-frame ray directions (binary32)
@@ -47,8 +55,8 @@ struct DeviceParams {
     CarState* cars;
     float* ranges;                // [n_cars][ranges_stride]
     int64_t* steps;               // [n_envs]
+    FtgpVehicle veh;              // host-side copy (kernels read the LDS image)
     double wheel_load[4];
-    FtgpVehicle veh;
 };
 
 // ---------------------------------------------------------------------------------------------

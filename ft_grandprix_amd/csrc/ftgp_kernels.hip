@@ -1,74 +1,135 @@
 // ftgp_kernels.hip -- HIP kernels of the ft_grandprix hot path for gfx950 (CDNA4, wave64).
 //
-//   ftgp_step_kernel   K5 policy -> K2 LiDAR sweep -> K1 integrate -> K3 lap progress, n_steps per launch.
-//                      One wave per car: the 64 lanes stride the car's rays (coalesced 256-B range stores),
-//                      the car's state lives in wave-uniform registers across all steps of the launch, the
-//                      previous scan is staged in LDS for the on-device driver, contact candidates and the
-//                      centre-line argmin are spread over lanes and resolved with wave reductions.
-//   ftgp_reset_kernel  K4 reset / spawn (+ progress at the spawn pose), one car per lane.
+//   ftgp_step_kernel   K5 driver -> K2 LiDAR sweep -> K1 integrate -> K3 lap progress, n_steps per launch.
+//       One workgroup per CU (up to 16 waves), one wave per car, persistent over all steps of the launch.
+//       Everything a step touches repeatedly is staged into LDS once per launch with coalesced 16-B loads:
+//       the track as a two-level grid over 8x8-pixel blocks (block distance field + rank table + 64-bit
+//       wall masks, ~60 KB), the centre-line, the ray table, each car's state record and its previous scan.
+//       The 64 lanes of a wave stride the car's rays (256-B coalesced range stores, the only per-step HBM
+//       traffic); contact candidates and the centre-line argmin are spread over lanes and resolved with
+//       wave-level min/max reductions; the driver's disparity masks come from wave ballots.
+//   ftgp_policy_kernel    K5 alone (ftgp_policy_eval).
+//   ftgp_reset_kernel     K4 reset / spawn (+ K3 at the spawn pose), one car per lane.
 //   ftgp_progress_kernel  K3 alone (after ftgp_set_pose), one car per lane.
 //   ftgp_metrics_kernel   per-GPU metrics record.
 //
 // Reference behaviour restated by each block is cited inline (paths relative to the reference repo).
-// The arithmetic follows the specification in DESIGN.md operation by operation (-ffp-contract=off; explicit
-// fmaf where the specification says "fma") so that results are bit-identical to the CPU oracle.
+// Arithmetic follows DESIGN.md operation by operation (-ffp-contract=off; fmaf only where the specification
+// says "fma"), so results are bit-identical to the CPU oracle.
 #include "ftgp_device.h"
+
+// vehicle constants as staged into LDS (kept out of SGPRs: the step loop would otherwise pin ~80 of them)
+struct VehLds { FtgpVehicle v; double wheel_load[4]; };
+
+struct LdsView {
+    const VehLds* veh;
+    const uint8_t* fine;      // 32 B per non-empty block: 4-bit chessboard distance to the nearest wall pixel (0 = wall)
+    const uint2* rank;        // per 32 blocks {non-empty bits, non-empty blocks before this word}
+    const double* path;
+    const uint8_t* coarse;    // 4 bits per block: chessboard distance in blocks to the nearest non-empty block (0 = non-empty)
+    const float* ray_bx;
+    const float* ray_by;
+};
+
+__host__ __device__ __forceinline__ int coarse_at(const DeviceParams& P, const LdsView& L, int bx, int by)
+{
+    const int q = by * P.nbx + bx;
+    return (L.coarse[q >> 1] >> ((q & 1) << 2)) & 15;
+}
+// per-pixel distance nibble of pixel (cx, cy) inside the NON-EMPTY block (bx, by)
+__host__ __device__ __forceinline__ int fine_at(const DeviceParams& P, const LdsView& L, int bx, int by, int cx, int cy)
+{
+    const uint2 r = L.rank[by * P.nwpr + (bx >> 5)];
+    const int idx = (int)r.y + __builtin_popcount(r.x & ((1u << (bx & 31)) - 1u));
+    const int n = ((cy & 7) << 3) | (cx & 7);
+    return (L.fine[(idx << 5) + (n >> 1)] >> ((n & 1) << 2)) & 15;
+}
+// wall bit of pixel (cx, cy), which must lie inside the image
+__host__ __device__ __forceinline__ bool grid_wall(const DeviceParams& P, const LdsView& L, int cx, int cy)
+{
+    const int bx = cx >> 3, by = cy >> 3;
+    if (coarse_at(P, L, bx, by) != 0) return false;
+    return fine_at(P, L, bx, by, cx, cy) == 0;
+}
 
 // =============================================================================================
 // K2: LiDAR
 // =============================================================================================
-
-// Variable-step DDA over the chessboard distance field: from cell (ix, iy) with field value k the
-// (2k-1)^2 block of cells around it is wall-free, so the ray jumps straight to that block's boundary.
-// With k == 1 this is the classic cell-by-cell DDA.
-__device__ __forceinline__ float march_f32(const DeviceParams& P, float pu, float pv, float du, float dv)
+// The specification of a ray is the plain cell-by-cell DDA (DESIGN.md "K2"): crossing times
+// sX(b) = ((float)b - pu) * (1/du), sY(b) = ((float)b - pv) * (1/dv); x-step iff sX < sY (a tie steps in y).
+// This march returns the same bits while skipping wall-free cells:
+//   * an empty 8x8 block with block distance c  -> the (2c-1)^2 blocks around it hold no wall;
+//   * a pixel of a non-empty block with distance k -> the (2k-1)^2 pixels around it hold no wall;
+//   in both cases the ray jumps to the far edge of that rectangle, and the coordinate of the other axis is the
+//   number of its boundaries the specification says were crossed by then (sY(b) <= s after an x-jump,
+//   sX(b) < s after a y-jump).  That count is floor(p + d*s) unless the landing point is within 2^-9 pixel of
+//   a boundary; only then are the specification's comparisons evaluated (rounding errors are < 6e-4 pixel for
+//   images up to 8192 pixels).
+// Both axes are mirrored so that the ray always travels towards +x', +y' (x' = -x is exact in IEEE arithmetic and
+// maps cell i to ~i, block b to ~b), which removes every direction-dependent select from the loop.
+__host__ __device__ __forceinline__ float march_grid(const DeviceParams& P, const LdsView& L, float pu, float pv, float du, float dv)
 {
     const int W = P.width, H = P.height;
-    int ix = (int)floorf(pu), iy = (int)floorf(pv);
-    if (ix < 0 || ix >= W || iy < 0 || iy >= H) return -1.0f;
+    const int ix0 = (int)floorf(pu), iy0 = (int)floorf(pv);
+    if (ix0 < 0 || ix0 >= W || iy0 < 0 || iy0 >= H) return -1.0f;
     const bool xnz = du != 0.0f, ynz = dv != 0.0f;
-    const bool xpos = du > 0.0f, ypos = dv > 0.0f;
-    const float inv_du = xnz ? 1.0f / du : 0.0f;
-    const float inv_dv = ynz ? 1.0f / dv : 0.0f;
-    const uint8_t* __restrict__ field = P.field;
-    float s = 0.0f;
-    for (int it = 0; it < 8192; ++it) {
-        const int k = field[iy * W + ix];
-        if (k == 0) return s;
-        const int bxi = xpos ? ix + k : ix - k + 1;
-        const int byi = ypos ? iy + k : iy - k + 1;
-        const float sX = xnz ? ((float)bxi - pu) * inv_du : INFINITY;
-        const float sY = ynz ? ((float)byi - pv) * inv_dv : INFINITY;
-        if (sX < sY) {
-            s = sX;
-            const int nix = xpos ? ix + k : ix - k;
-            int t = (int)floorf(fmaf(dv, s, pv));
-            const int lo = iy - k + 1, hi = iy + k - 1;
-            iy = t < lo ? lo : (t > hi ? hi : t);
-            ix = nix;
+    const int mx = du < 0.0f ? -1 : 0, my = dv < 0.0f ? -1 : 0;
+    const float pum = mx ? -pu : pu, pvm = my ? -pv : pv;
+    const float dum = fabsf(du), dvm = fabsf(dv);
+    const float ivx = xnz ? fabsf(1.0f / du) : 0.0f, ivy = ynz ? fabsf(1.0f / dv) : 0.0f;
+    const float eps = P.snap_eps, one_m_eps = 1.0f - P.snap_eps;
+    int ix = ix0 ^ mx, iy = iy0 ^ my;      // mirrored cell indices
+    float s = 0.0f, result = -1.0f;
+    bool active = true;
+    for (int guard = 0; guard < 4096 && active; ++guard) {
+        const int tx = ix ^ mx, ty = iy ^ my;                       // true pixel
+        const int bx = tx >> 3, by = ty >> 3;
+        const int c = coarse_at(P, L, bx, by);
+        int xhi, yhi;
+        if (c == 0) {
+            const int k = fine_at(P, L, bx, by, tx, ty);
+            if (k == 0) { result = fabsf(s); active = false; break; }   // wall pixel: the crossing time that entered it
+            xhi = ix + k - 1; yhi = iy + k - 1;
         } else {
-            s = sY;
-            const int niy = ypos ? iy + k : iy - k;
-            int t = (int)floorf(fmaf(du, s, pu));
-            const int lo = ix - k + 1, hi = ix + k - 1;
-            ix = t < lo ? lo : (t > hi ? hi : t);
-            iy = niy;
+            xhi = (((ix >> 3) + c) << 3) - 1; yhi = (((iy >> 3) + c) << 3) - 1;
         }
-        if (ix < 0 || ix >= W || iy < 0 || iy >= H) return -1.0f;
+        const float sX = xnz ? ((float)(xhi + 1) - pum) * ivx : INFINITY;
+        const float sY = ynz ? ((float)(yhi + 1) - pvm) * ivy : INFINITY;
+        const bool stepx = sX < sY;
+        s = stepx ? sX : sY;
+        const float tp = stepx ? pvm : pum, td = stepx ? dvm : dum;
+        const int cur = stepx ? iy : ix, hi = stepx ? yhi : xhi;
+        const float v = fmaf(td, s, tp);
+        const float fl = floorf(v);
+        int t = (int)fl;
+        t = t < cur ? cur : (t > hi ? hi : t);
+        const float frac = v - fl;
+        if (!(frac >= eps && frac <= one_m_eps)) {
+            // within eps of a boundary: ask the specification
+            const float tinv = stepx ? ivy : ivx;
+            const float Sa = ((float)t - tp) * tinv, Sb = ((float)(t + 1) - tp) * tinv;
+            const bool ca = stepx ? (Sa <= s) : (Sa < s), cb = stepx ? (Sb <= s) : (Sb < s);
+            const bool dec = (t > cur) & !ca;
+            const bool inc = !dec & (t < hi) & cb;
+            t += (inc ? 1 : 0) - (dec ? 1 : 0);
+        }
+        t = (stepx ? ynz : xnz) ? t : cur;
+        ix = stepx ? xhi + 1 : t;
+        iy = stepx ? t : yhi + 1;
+        const int nx = ix ^ mx, ny = iy ^ my;
+        active = nx >= 0 && nx < W && ny >= 0 && ny < H;           // leaving the image: -1
     }
-    return -1.0f;
+    return result;
 }
 
-// Pose of a car as seen by the other cars of its env (pre-step state, published through LDS).
-struct PubPose { double x, y, qw, qz, vx, vy, wz, pad; };
-
 // Ray against another car: chassis box (slab test) and LiDAR puck (circle), binary32.
-__device__ __forceinline__ float ray_vs_car(const FtgpVehicle& v, const PubPose& b, double lcx, double lcy, float dxw, float dyw)
+__device__ __forceinline__ float ray_vs_car(const FtgpVehicle& v, const CarCore* b, double lcx, double lcy, float dxw, float dyw)
 {
     const float r0 = (float)v.lidar_ring_radius;
     float best = INFINITY;
-    const double cb = 1.0 - 2.0 * (b.qz * b.qz), sb = 2.0 * (b.qw * b.qz);
-    const float relx = (float)(lcx - b.x), rely = (float)(lcy - b.y);
+    const double bqw = b->qw, bqz = b->qz;
+    const double cb = 1.0 - 2.0 * (bqz * bqz), sb = 2.0 * (bqw * bqz);
+    const float relx = (float)(lcx - b->x), rely = (float)(lcy - b->y);
     const float ox = fmaf(dxw, -r0, relx), oy = fmaf(dyw, -r0, rely);
     const float cbf = (float)cb, sbf = (float)sb;
     const float lx = fmaf(cbf, ox, sbf * oy), ly = fmaf(cbf, oy, -(sbf * ox));
@@ -107,13 +168,14 @@ __device__ __forceinline__ float ray_vs_car(const FtgpVehicle& v, const PubPose&
 // the ring at centre - 0.03*dir_j, dir_j = R(yaw) * (sin phi_j, -cos phi_j); j = 0 is the rear, CCW.
 // Values replace data.sensordata[vehicle_state.sensors] (custom.py:1395).
 template <bool MULTI>
-__device__ __forceinline__ void lidar_sweep(const DeviceParams& P, const CarCore& s, float* __restrict__ out_global,
-                                            float* __restrict__ out_lds, const PubPose* pub, int my_slot)
+__device__ __forceinline__ void lidar_sweep(const DeviceParams& P, const LdsView& L, const CarCore* st, float* __restrict__ out_global,
+                                            float* __restrict__ out_lds, const CarCore* env_cars, int my_slot)
 {
-    const FtgpVehicle& v = P.veh;
-    const double ch = 1.0 - 2.0 * (s.qz * s.qz), sh = 2.0 * (s.qw * s.qz);
-    const double lcx = s.x + (ch * v.lidar_x - sh * v.lidar_y);
-    const double lcy = s.y + (sh * v.lidar_x + ch * v.lidar_y);
+    const FtgpVehicle& v = L.veh->v;
+    const double qw = st->qw, qz = st->qz;
+    const double ch = 1.0 - 2.0 * (qz * qz), sh = 2.0 * (qw * qz);
+    const double lcx = st->x + (ch * v.lidar_x - sh * v.lidar_y);
+    const double lcy = st->y + (sh * v.lidar_x + ch * v.lidar_y);
     const float u0 = (float)((lcx - P.origin_x) * P.inv_px_x);
     const float v0 = (float)((P.origin_y - lcy) * P.inv_px_y);
     const float chf = (float)ch, shf = (float)sh;
@@ -124,31 +186,36 @@ __device__ __forceinline__ void lidar_sweep(const DeviceParams& P, const CarCore
     for (int base = 0; base < R; base += FTGP_WAVE) {
         const int j = base + lane;
         if (j < R) {
-            const float bx = P.ray_bx[j], by = P.ray_by[j];
+            const float bx = L.ray_bx[j], by = L.ray_by[j];
             const float dxw = fmaf(chf, bx, -(shf * by));
             const float dyw = fmaf(shf, bx, chf * by);
             const float du = dxw * isx;
             const float dv = -(dyw * isy);
             const float pu = fmaf(du, -r0, u0);
             const float pv = fmaf(dv, -r0, v0);
-            float r = march_f32(P, pu, pv, du, dv);
+            float r = march_grid(P, L, pu, pv, du, dv);
             if (MULTI) {
                 for (int k = 0; k < P.cars_per_env; ++k) {
                     if (k == my_slot) continue;
-                    const float rc = ray_vs_car(v, pub[k], lcx, lcy, dxw, dyw);
+                    const float rc = ray_vs_car(v, env_cars + k, lcx, lcy, dxw, dyw);
                     if (rc < INFINITY && (r < 0.0f || rc < r)) r = rc;
                 }
             }
             out_global[j] = r;
-            if (out_lds) out_lds[j] = r;
+            if (out_lds) {      // the on-device driver only reads ranges[0] and ranges[eighth : n - eighth]
+                if (j == 0) out_lds[0] = r;
+                if (j >= P.eighth && j < R - P.eighth) out_lds[1 + j - P.eighth] = r;
+            }
         }
     }
 }
 
 // =============================================================================================
-// K3: lap progress (custom.py:1340-1372), wave-cooperative argmin over the 100 centre-line points
+// K3: lap progress (custom.py:1340-1372)
 // =============================================================================================
-__device__ __forceinline__ void progress_update(const DeviceParams& P, CarCore& s, int64_t steps, int closest, double best, double* __restrict__ times)
+struct Race { int32_t completion, laps, start, offset, good_start, finished, off_track, delta, n_times; double dist2; };
+
+__device__ __forceinline__ void progress_update(const DeviceParams& P, Race& s, int64_t steps, int closest, double best, double* __restrict__ times)
 {
     s.dist2 = best;                                       // custom.py:1343 (squared)
     s.off_track = best > 1.0;                             // custom.py:1344
@@ -176,16 +243,31 @@ __device__ __forceinline__ void progress_update(const DeviceParams& P, CarCore& 
     s.completion = completion;
 }
 
-__device__ __forceinline__ void progress_wave(const DeviceParams& P, CarCore& s, int64_t steps, double* __restrict__ times)
+__device__ __forceinline__ void race_load(Race& r, const CarCore* st)
+{
+    r.completion = st->completion; r.laps = st->laps; r.start = st->start; r.offset = st->offset;
+    r.good_start = st->good_start; r.finished = st->finished; r.off_track = st->off_track; r.delta = st->delta;
+    r.n_times = st->n_times; r.dist2 = st->dist2;
+}
+__device__ __forceinline__ void race_store(const Race& r, CarCore* st)
+{
+    st->completion = r.completion; st->laps = r.laps; st->start = r.start;
+    st->good_start = r.good_start; st->finished = r.finished; st->off_track = r.off_track; st->delta = r.delta;
+    st->n_times = r.n_times; st->dist2 = r.dist2;
+}
+
+// wave-cooperative: argmin over the 100 centre-line points (first minimum), then the race-state update
+__device__ __forceinline__ void progress_wave(const DeviceParams& P, const double* __restrict__ path, CarCore* st, int64_t steps, double* __restrict__ times)
 {
     const int lane = lane_id();
-    // distances = ((path - xpos)**2).sum(1); closest = distances.argmin()   (first minimum)
+    const double x = st->x, y = st->y;
+    // distances = ((path - xpos)**2).sum(1); closest = distances.argmin()
     double best = INFINITY; int idx = 0x7fffffff;
     #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int i = lane + h * FTGP_WAVE;
         if (i < FTGP_PATH_POINTS) {
-            const double dx = P.path[2 * i] - s.x, dy = P.path[2 * i + 1] - s.y;
+            const double dx = path[2 * i] - x, dy = path[2 * i + 1] - y;
             const double d = dx * dx + dy * dy;
             if (d < best) { best = d; idx = i; }
         }
@@ -196,24 +278,28 @@ __device__ __forceinline__ void progress_wave(const DeviceParams& P, CarCore& s,
         const int oi = __shfl_xor(idx, m, FTGP_WAVE);
         if (ob < best || (ob == best && oi < idx)) { best = ob; idx = oi; }
     }
-    progress_update(P, s, steps, idx, best, times);
+    Race r; race_load(r, st);
+    progress_update(P, r, steps, idx, best, times);
+    if (lane == 0) race_store(r, st);
 }
 
 // =============================================================================================
 // K1: integrate one dt (reduced planar model of template/mushr.em.xml stepped by mj_step, custom.py:1425)
 // =============================================================================================
 struct Force { double fx, fy, tz; };
+struct Dyn { double x, y, qw, qz, vx, vy, wz, qs, qsd, w[4]; };
 
 // Chassis circles against wall pixels: the (2nx+1) x (2ny+1) candidate cells of each circle are tested
 // one per lane; the deepest penetration (ties: first in raster order) is picked by a wave reduction.
-__device__ __forceinline__ void wall_contact(const DeviceParams& P, const CarCore& s, double ch, double sh, Force& f)
+__device__ __forceinline__ void wall_contact(const DeviceParams& P, const LdsView& L, const Dyn& s, double ch, double sh, Force& f)
 {
-    const FtgpVehicle& v = P.veh;
+    const FtgpVehicle& v = L.veh->v;
     const int W = P.width, H = P.height;
     const double sx = P.px_size_x, sy = P.px_size_y;
     const double r = v.contact_radius;
     const int nx = (int)ceil(r * P.inv_px_x), ny = (int)ceil(r * P.inv_px_y);
     const int reach = (nx > ny ? nx : ny) + 1;
+    const int need = ((reach + 7) >> 3) + 1;     // block distance at which no wall pixel can be within reach
     const int wx = 2 * nx + 1, ncell = wx * (2 * ny + 1);
     const int lane = lane_id();
     for (int k = 0; k < 3; ++k) {
@@ -222,14 +308,13 @@ __device__ __forceinline__ void wall_contact(const DeviceParams& P, const CarCor
         const double u = (px - P.origin_x) * P.inv_px_x, w = (P.origin_y - py) * P.inv_px_y;
         const int ix = (int)floor(u), iy = (int)floor(w);
         if (ix < 0 || ix >= W || iy < 0 || iy >= H) continue;
-        if ((int)P.field[iy * W + ix] > reach) continue;
+        if (coarse_at(P, L, ix >> 3, iy >> 3) >= need) continue;
         double mypen = 0.0; int myc = 0x7fffffff;
         for (int base = 0; base < ncell; base += FTGP_WAVE) {
             const int c = base + lane;
             if (c < ncell) {
                 const int cy = iy + (c / wx - ny), cx = ix + (c % wx - nx);
-                if (cx >= 0 && cx < W && cy >= 0 && cy < H &&
-                    ((P.bits[cy * P.words_per_row + (cx >> 5)] >> (cx & 31)) & 1u)) {
+                if (cx >= 0 && cx < W && cy >= 0 && cy < H && grid_wall(P, L, cx, cy)) {
                     const double x0 = P.origin_x + (double)cx * sx, x1 = x0 + sx;
                     const double y1 = P.origin_y - (double)cy * sy, y0 = y1 - sy;
                     const double qx = px < x0 ? x0 : (px > x1 ? x1 : px);
@@ -275,28 +360,29 @@ __device__ __forceinline__ void wall_contact(const DeviceParams& P, const CarCor
 }
 
 // Circles of this car against the circles of the other cars of the env (penalty spring/damper).
-__device__ __forceinline__ void car_contact(const DeviceParams& P, const CarCore& s, double ch, double sh,
-                                            const PubPose* pub, int my_slot, Force& f)
+__device__ __forceinline__ void car_contact(const DeviceParams& P, const LdsView& L, const Dyn& s, double ch, double sh,
+                                            const CarCore* env_cars, int my_slot, Force& f)
 {
-    const FtgpVehicle& v = P.veh;
+    const FtgpVehicle& v = L.veh->v;
     const double r2 = 2.0 * v.contact_radius;
     for (int k = 0; k < P.cars_per_env; ++k) {
         if (k == my_slot) continue;
-        const PubPose b = pub[k];
-        const double cb = 1.0 - 2.0 * (b.qz * b.qz), sb = 2.0 * (b.qw * b.qz);
+        const CarCore* b = env_cars + k;
+        const double bx = b->x, by = b->y, bqw = b->qw, bqz = b->qz, bvx = b->vx, bvy = b->vy, bwz = b->wz;
+        const double cb = 1.0 - 2.0 * (bqz * bqz), sb = 2.0 * (bqw * bqz);
         for (int i = 0; i < 3; ++i) {
             const double rxw = ch * v.contact_x[i], ryw = sh * v.contact_x[i];
             const double px = s.x + rxw, py = s.y + ryw;
             const double vax = s.vx - s.wz * ryw, vay = s.vy + s.wz * rxw;
             for (int j = 0; j < 3; ++j) {
                 const double sxw = cb * v.contact_x[j], syw = sb * v.contact_x[j];
-                const double qx = b.x + sxw, qy = b.y + syw;
+                const double qx = bx + sxw, qy = by + syw;
                 const double ex = px - qx, ey = py - qy;
                 const double d2 = ex * ex + ey * ey;
                 if (d2 >= r2 * r2 || d2 <= 0.0) continue;
                 const double d = sqrt(d2);
                 const double nxv = ex / d, nyv = ey / d;
-                const double vbx = b.vx - b.wz * syw, vby = b.vy + b.wz * sxw;
+                const double vbx = bvx - bwz * syw, vby = bvy + bwz * sxw;
                 const double vn = (vax - vbx) * nxv + (vay - vby) * nyv;
                 const double mag = v.contact_stiffness * (r2 - d) - v.contact_damping * vn;
                 if (mag <= 0.0) continue;
@@ -307,11 +393,16 @@ __device__ __forceinline__ void car_contact(const DeviceParams& P, const CarCore
     }
 }
 
+// new dynamic state from the pre-step state in LDS (other cars of the env are read pre-step too)
 template <bool MULTI>
-__device__ __forceinline__ void integrate(const DeviceParams& P, CarCore& s, const PubPose* pub, int my_slot)
+__device__ __forceinline__ Dyn integrate(const DeviceParams& P, const LdsView& L, const CarCore* st, const CarCore* env_cars, int my_slot)
 {
-    const FtgpVehicle& v = P.veh;
+    const FtgpVehicle& v = L.veh->v;
     const double dt = P.dt;
+    Dyn s;
+    s.x = st->x; s.y = st->y; s.qw = st->qw; s.qz = st->qz; s.vx = st->vx; s.vy = st->vy; s.wz = st->wz;
+    s.qs = st->qs; s.qsd = st->qsd; s.w[0] = st->w[0]; s.w[1] = st->w[1]; s.w[2] = st->w[2]; s.w[3] = st->w[3];
+    const double u_speed = st->u_speed, u_steer = st->u_steer;
     const double ch = 1.0 - 2.0 * (s.qz * s.qz), sh = 2.0 * (s.qw * s.qz);
     // Ackermann coupling, mushr.em.xml:185-186
     const double q = s.qs;
@@ -321,12 +412,12 @@ __device__ __forceinline__ void integrate(const DeviceParams& P, CarCore& s, con
     const double sw[4] = { spec_sin(dfl), spec_sin(dfr), 0.0, 0.0 };
     // velocity servo on the tendon = mean wheel spin, mushr.em.xml:180,191-196
     const double wbar = 0.25 * (((s.w[0] + s.w[1]) + s.w[2]) + s.w[3]);
-    double fa = v.throttle_kv * (s.u_speed - v.throttle_gear * wbar);
+    double fa = v.throttle_kv * (u_speed - v.throttle_gear * wbar);
     if (fa > v.throttle_force_limit) fa = v.throttle_force_limit;
     if (fa < -v.throttle_force_limit) fa = -v.throttle_force_limit;
     const double ta = (v.throttle_gear * 0.25) * fa;
     Force f = { 0.0, 0.0, 0.0 };
-    double wn[4];
+    Dyn o;
     #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const double rxw = ch * v.wheel_x[i] - sh * v.wheel_y[i];
@@ -336,41 +427,46 @@ __device__ __forceinline__ void integrate(const DeviceParams& P, CarCore& s, con
         const double vlong = (vpx * fdx + vpy * fdy) - v.wheel_radius * s.w[i];
         const double vlat = vpy * fdx - vpx * fdy;
         double flong = -(v.tire_damping * vlong), flat = -(v.tire_damping * vlat);
-        const double lim = v.friction * P.wheel_load[i];
+        const double lim = v.friction * L.veh->wheel_load[i];
         const double m2 = flong * flong + flat * flat;
         if (m2 > lim * lim) { const double sc = lim / sqrt(m2); flong = flong * sc; flat = flat * sc; }
         const double fx = flong * fdx - flat * fdy, fy = flong * fdy + flat * fdx;
         f.fx += fx; f.fy += fy; f.tz += rxw * fy - ryw * fx;
-        wn[i] = (v.wheel_inertia * s.w[i] + dt * (ta - v.wheel_radius * flong)) / (v.wheel_inertia + dt * v.wheel_damping);
+        o.w[i] = (v.wheel_inertia * s.w[i] + dt * (ta - v.wheel_radius * flong)) / (v.wheel_inertia + dt * v.wheel_damping);
     }
-    wall_contact(P, s, ch, sh, f);
-    if (MULTI) car_contact(P, s, ch, sh, pub, my_slot, f);
-    const double nvx = s.vx + dt * (f.fx / v.mass);
-    const double nvy = s.vy + dt * (f.fy / v.mass);
-    const double nwz = s.wz + dt * (f.tz / v.izz);
+    wall_contact(P, L, s, ch, sh, f);
+    if (MULTI) car_contact(P, L, s, ch, sh, env_cars, my_slot, f);
+    o.vx = s.vx + dt * (f.fx / v.mass);
+    o.vy = s.vy + dt * (f.fy / v.mass);
+    o.wz = s.wz + dt * (f.tz / v.izz);
     // position servo on the steering joint, implicit damping (mushr.em.xml:78,179)
-    double nqsd = (v.steer_inertia * s.qsd + dt * (v.steer_kp * (s.u_steer - s.qs))) / (v.steer_inertia + dt * v.steer_damping);
-    double nqs = s.qs + dt * nqsd;
-    if (nqs > v.steer_limit) { nqs = v.steer_limit; if (nqsd > 0.0) nqsd = 0.0; }
-    if (nqs < -v.steer_limit) { nqs = -v.steer_limit; if (nqsd < 0.0) nqsd = 0.0; }
+    o.qsd = (v.steer_inertia * s.qsd + dt * (v.steer_kp * (u_steer - s.qs))) / (v.steer_inertia + dt * v.steer_damping);
+    o.qs = s.qs + dt * o.qsd;
+    if (o.qs > v.steer_limit) { o.qs = v.steer_limit; if (o.qsd > 0.0) o.qsd = 0.0; }
+    if (o.qs < -v.steer_limit) { o.qs = -v.steer_limit; if (o.qsd < 0.0) o.qsd = 0.0; }
     // semi-implicit Euler: positions with the new velocities
-    const double h = (0.5 * dt) * nwz;
+    const double h = (0.5 * dt) * o.wz;
     const double chh = spec_cos(h), shh = spec_sin(h);
     const double nw = s.qw * chh - s.qz * shh, nz = s.qz * chh + s.qw * shh;
     const double n = sqrt(nw * nw + nz * nz);
-    s.x = s.x + dt * nvx;
-    s.y = s.y + dt * nvy;
-    s.qw = nw / n; s.qz = nz / n;
-    s.vx = nvx; s.vy = nvy; s.wz = nwz;
-    s.qs = nqs; s.qsd = nqsd;
-    #pragma unroll
-    for (int i = 0; i < 4; ++i) s.w[i] = wn[i];
+    o.x = s.x + dt * o.vx;
+    o.y = s.y + dt * o.vy;
+    o.qw = nw / n; o.qz = nz / n;
+    return o;
+}
+
+__device__ __forceinline__ void dyn_store(const Dyn& o, CarCore* st)
+{
+    st->x = o.x; st->y = o.y; st->qw = o.qw; st->qz = o.qz; st->vx = o.vx; st->vy = o.vy; st->wz = o.wz;
+    st->qs = o.qs; st->qsd = o.qsd; st->w[0] = o.w[0]; st->w[1] = o.w[1]; st->w[2] = o.w[2]; st->w[3] = o.w[3];
 }
 
 // =============================================================================================
 // K5: on-device drivers.  nidc.py:12-131 / fast.py:11-139 restated for one wave; the previous scan sits in LDS.
 // =============================================================================================
-__device__ __forceinline__ void policy_disparity(const DeviceParams& P, float* __restrict__ scan, CarCore& s, bool fast)
+struct Ctrl { double speed, steer, last_steer; };
+
+__device__ __forceinline__ void policy_disparity(const DeviceParams& P, float* __restrict__ scan, Ctrl& ctl, bool fast)
 {
     const int lane = lane_id();
     const int n = P.n_rays;
@@ -378,8 +474,9 @@ __device__ __forceinline__ void policy_disparity(const DeviceParams& P, float* _
     const double rpp = (2 * M_PI) / (double)n;                      // nidc.py:121
     const int eighth = (int)((double)n / 8.0);                      // nidc.py:18
     const int m = n - 2 * eighth;
-    float* __restrict__ proc = scan + eighth;                       // nidc.py:19 (the copy is the LDS image itself)
-    const float range0 = scan[0];
+    float* __restrict__ proc = scan + 1;                            // nidc.py:19: ranges[eighth:-eighth] (the copy is the LDS image)
+    const float range0 = scan[0];                                   // ranges[0], fast.py:135
+    const double width = (car_width / 2) * (1 + 300.0 / 100);       // nidc.py:93
     // disparities on the UNMODIFIED scan (nidc.py:26-40): one ballot per 64 elements, parked in lane (pass)
     uint64_t mymask = 0;
     const int npass = (m + FTGP_WAVE - 1) / FTGP_WAVE;
@@ -392,10 +489,9 @@ __device__ __forceinline__ void policy_disparity(const DeviceParams& P, float* _
         if ((p & 63) == 63 || p == npass - 1) {
             // flush this group of up to 64 ballots: extend the disparities in index order (nidc.py:86-105)
             const int p0 = p & ~63;
-            const double width = (car_width / 2) * (1 + 300.0 / 100);  // nidc.py:93
             for (int pp = p0; pp <= p; ++pp) {
-                uint32_t lo = __builtin_amdgcn_readlane((uint32_t)mymask, pp & 63);
-                uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(mymask >> 32), pp & 63);
+                const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)mymask, pp & 63);
+                const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(mymask >> 32), pp & 63);
                 uint64_t mask = ((uint64_t)hi << 32) | lo;
                 while (mask) {
                     const int bit = __builtin_ctzll(mask);
@@ -441,29 +537,62 @@ __device__ __forceinline__ void policy_disparity(const DeviceParams& P, float* _
         speed = 0.5 * 5 * (1 - fabs(ang) / (1.57 * 2));             // nidc.py:130
     } else {
         const double old = 0.0;                                     // fast.py:131-133
-        ang = s.last_steer * old + ang * (1 - old);
-        s.last_steer = ang;
+        ang = ctl.last_steer * old + ang * (1 - old);
+        ctl.last_steer = ang;
         if (fabs(ang) < 0.1 && (double)range0 > 0.5) speed = 7.0;   // fast.py:135-138
         else { const double sp = 0.5 * 5 * (1 - fabs(ang) / M_PI); speed = sp < 2.0 ? sp : 2.0; }
     }
-    s.u_speed = speed; s.u_steer = ang;
+    ctl.speed = speed; ctl.steer = ang;
 }
 
-__device__ __forceinline__ void policy_apply(const DeviceParams& P, int policy, float* scan, CarCore& s, int ci, int64_t steps)
+// evaluates the driver of car ci and stores the controls into its state record
+__device__ __forceinline__ void policy_apply(const DeviceParams& P, int policy, float* scan, CarCore* st, int ci, int64_t steps)
 {
-    if (s.finished) { s.u_speed = 0.0; s.u_steer = 0.0; return; }  // finished cars get the null driver (custom.py:1446)
-    switch (policy) {
-    case FTGP_POLICY_LOBOTOMY: s.u_speed = 0.0; s.u_steer = 0.0; break;   // lobotomy.py:2-3
-    case FTGP_POLICY_NIDC: policy_disparity(P, scan, s, false); break;
-    case FTGP_POLICY_FAST: policy_disparity(P, scan, s, true); break;
+    Ctrl c; c.speed = st->u_speed; c.steer = st->u_steer; c.last_steer = st->last_steer;
+    if (st->finished) { c.speed = 0.0; c.steer = 0.0; }             // finished cars get the null driver (custom.py:1446)
+    else switch (policy) {
+    case FTGP_POLICY_LOBOTOMY: c.speed = 0.0; c.steer = 0.0; break;   // lobotomy.py:2-3
+    case FTGP_POLICY_NIDC: policy_disparity(P, scan, c, false); break;
+    case FTGP_POLICY_FAST: policy_disparity(P, scan, c, true); break;
     case FTGP_POLICY_RANDOM: {
         uint64_t h = splitmix64(P.seed + (uint64_t)ci * 0x9E3779B97F4A7C15ull);
         h = splitmix64(h ^ (uint64_t)steps);
-        s.u_speed = 3.0 * u01(h);
-        s.u_steer = 2.0 * u01(splitmix64(h)) - 1.0;
+        c.speed = 3.0 * u01(h);
+        c.steer = 2.0 * u01(splitmix64(h)) - 1.0;
         break; }
     default: break;
     }
+    if (lane_id() == 0) { st->u_speed = c.speed; st->u_steer = c.steer; st->last_steer = c.last_steer; }
+}
+
+// =============================================================================================
+// LDS staging
+// =============================================================================================
+__device__ __forceinline__ void stage16(void* dst, const void* src, int bytes)
+{
+    const uint4* s4 = reinterpret_cast<const uint4*>(src);
+    uint4* d4 = reinterpret_cast<uint4*>(dst);
+    const int n = bytes >> 4;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) d4[i] = s4[i];
+}
+
+__device__ __forceinline__ LdsView stage_track(const DeviceParams& P, unsigned char* lds)
+{
+    stage16(lds + P.off_veh, P.veh_dev, P.off_fine - P.off_veh);
+    stage16(lds + P.off_fine, P.fine, P.off_rank - P.off_fine);
+    stage16(lds + P.off_rank, P.rank, P.off_path - P.off_rank);
+    stage16(lds + P.off_path, P.path, P.off_coarse - P.off_path);
+    stage16(lds + P.off_coarse, P.coarse, P.off_ray - P.off_coarse);
+    stage16(lds + P.off_ray, P.ray_bx, P.off_state - P.off_ray);    // ray_bx and ray_by are one allocation
+    LdsView L;
+    L.veh = reinterpret_cast<const VehLds*>(lds + P.off_veh);
+    L.fine = lds + P.off_fine;
+    L.rank = reinterpret_cast<const uint2*>(lds + P.off_rank);
+    L.path = reinterpret_cast<const double*>(lds + P.off_path);
+    L.coarse = lds + P.off_coarse;
+    L.ray_bx = reinterpret_cast<const float*>(lds + P.off_ray);
+    L.ray_by = L.ray_bx + P.ray_floats;
+    return L;
 }
 
 // =============================================================================================
@@ -472,77 +601,88 @@ __device__ __forceinline__ void policy_apply(const DeviceParams& P, int policy, 
 //   progress at the new pose (= the head of the next loop iteration).
 // =============================================================================================
 template <bool MULTI>
-__global__ void __launch_bounds__(MULTI ? 512 : 256, MULTI ? 2 : 4) ftgp_step_kernel(DeviceParams P, int policy, int n_steps, int cars_per_block)
+__global__ void __launch_bounds__(1024) ftgp_step_kernel(DeviceParams P, int policy, int n_steps, int cars_per_block)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ci = __builtin_amdgcn_readfirstlane((int)blockIdx.x * cars_per_block + wave);
     const bool live = ci < P.n_cars;
     const int env = live ? ci / P.cars_per_env : 0;
-    const int my_slot = MULTI ? wave : 0;   // MULTI: one env per block, wave == car slot
+    const int my_slot = MULTI ? wave % P.cars_per_env : 0;
     const bool need_scan = (policy == FTGP_POLICY_NIDC || policy == FTGP_POLICY_FAST);
-    const int scan_floats = (P.n_rays + 3) & ~3;
-    float* scan = need_scan ? reinterpret_cast<float*>(lds_raw) + wave * scan_floats : nullptr;
-    PubPose* pub = reinterpret_cast<PubPose*>(lds_raw + (need_scan ? (size_t)cars_per_block * scan_floats * sizeof(float) : 0));
+    const int scan_floats = P.scan_floats;
 
-    CarCore s;
+    const LdsView L = stage_track(P, lds);
+    CarCore* states = reinterpret_cast<CarCore*>(lds + P.off_state);
+    CarCore* st = states + wave;
+    const CarCore* env_cars = states + (wave - my_slot);
+    float* scan = need_scan ? reinterpret_cast<float*>(lds + P.off_scan) + wave * scan_floats : nullptr;
+
     int64_t steps = 0;
     float* my_ranges = nullptr;
     if (live) {
-        s = static_cast<const CarCore&>(P.cars[ci]);
+        if (lane < (int)(sizeof(CarCore) / 4))
+            reinterpret_cast<uint32_t*>(st)[lane] = reinterpret_cast<const uint32_t*>(static_cast<const CarCore*>(&P.cars[ci]))[lane];
         steps = P.steps[env];
         my_ranges = P.ranges + (size_t)ci * P.ranges_stride;
         if (need_scan) {
-            for (int j = lane; j < P.n_rays; j += FTGP_WAVE) scan[j] = my_ranges[j];
+            if (lane == 0) scan[0] = my_ranges[0];
+            for (int j = P.eighth + lane; j < P.n_rays - P.eighth; j += FTGP_WAVE) scan[1 + j - P.eighth] = my_ranges[j];
         }
     }
+    __syncthreads();
+
     for (int it = 0; it < n_steps; ++it) {
         if (live) {
             if (policy != FTGP_POLICY_HOST) {
-                if (need_scan) wave_lds_sync();
-                policy_apply(P, policy, scan, s, ci, steps);
+                policy_apply(P, policy, scan, st, ci, steps);
+                wave_lds_sync();
             }
+            lidar_sweep<MULTI>(P, L, st, my_ranges, scan, env_cars, my_slot);   // sensors at the pre-integration pose
         }
-        if (MULTI) {
-            if (live && lane == 0) {
-                PubPose pp; pp.x = s.x; pp.y = s.y; pp.qw = s.qw; pp.qz = s.qz; pp.vx = s.vx; pp.vy = s.vy; pp.wz = s.wz; pp.pad = 0.0;
-                pub[my_slot] = pp;
-            }
-            __syncthreads();
-        }
+        Dyn nxt;
+        if (live) nxt = integrate<MULTI>(P, L, st, env_cars, my_slot);
+        if (MULTI) __syncthreads();          // every car of the env has read the pre-step states
         if (live) {
-            lidar_sweep<MULTI>(P, s, my_ranges, scan, pub, my_slot);   // sensors at the pre-integration pose
-            integrate<MULTI>(P, s, pub, my_slot);
+            if (lane == 0) dyn_store(nxt, st);
+            wave_lds_sync();
             steps += 1;
-            progress_wave(P, s, steps, P.cars[ci].times);
+            progress_wave(P, L.path, st, steps, P.cars[ci].times);
+            wave_lds_sync();
         }
-        if (MULTI) __syncthreads();   // everybody has read pub before the next step overwrites it
+        if (MULTI) __syncthreads();          // new states visible before the next step reads them
     }
-    if (live && lane == 0) {
-        static_cast<CarCore&>(P.cars[ci]) = s;
-        if (ci % P.cars_per_env == 0) P.steps[env] = steps;
+    if (live) {
+        wave_lds_sync();
+        if (lane < (int)(sizeof(CarCore) / 4))
+            reinterpret_cast<uint32_t*>(static_cast<CarCore*>(&P.cars[ci]))[lane] = reinterpret_cast<const uint32_t*>(st)[lane];
+        if (lane == 0 && ci % P.cars_per_env == 0) P.steps[env] = steps;
     }
 }
 
 // K5 alone: one wave per car evaluates the driver on the scan stored in P.ranges (ftgp_policy_eval).
 __global__ void __launch_bounds__(256) ftgp_policy_kernel(DeviceParams P, int policy, double* __restrict__ ctrl_out)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ci = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + wave);
     if (ci >= P.n_cars) return;
-    const int scan_floats = (P.n_rays + 3) & ~3;
-    float* scan = reinterpret_cast<float*>(lds_raw) + wave * scan_floats;
+    const int scan_floats = P.scan_floats;
+    CarCore* st = reinterpret_cast<CarCore*>(lds) + wave;
+    float* scan = reinterpret_cast<float*>(lds + 4 * sizeof(CarCore)) + wave * scan_floats;
     const float* my_ranges = P.ranges + (size_t)ci * P.ranges_stride;
-    for (int j = lane; j < P.n_rays; j += FTGP_WAVE) scan[j] = my_ranges[j];
+    if (lane == 0) scan[0] = my_ranges[0];
+    for (int j = P.eighth + lane; j < P.n_rays - P.eighth; j += FTGP_WAVE) scan[1 + j - P.eighth] = my_ranges[j];
+    if (lane < (int)(sizeof(CarCore) / 4))
+        reinterpret_cast<uint32_t*>(st)[lane] = reinterpret_cast<const uint32_t*>(static_cast<const CarCore*>(&P.cars[ci]))[lane];
     wave_lds_sync();
-    CarCore s = static_cast<const CarCore&>(P.cars[ci]);
-    policy_apply(P, policy, scan, s, ci, P.steps[ci / P.cars_per_env]);
+    policy_apply(P, policy, scan, st, ci, P.steps[ci / P.cars_per_env]);
+    wave_lds_sync();
     if (lane == 0) {
-        P.cars[ci].u_speed = s.u_speed; P.cars[ci].u_steer = s.u_steer; P.cars[ci].last_steer = s.last_steer;
-        if (ctrl_out) { ctrl_out[2 * ci] = s.u_speed; ctrl_out[2 * ci + 1] = s.u_steer; }
+        P.cars[ci].u_speed = st->u_speed; P.cars[ci].u_steer = st->u_steer; P.cars[ci].last_steer = st->last_steer;
+        if (ctrl_out) { ctrl_out[2 * ci] = st->u_speed; ctrl_out[2 * ci + 1] = st->u_steer; }
     }
 }
 
@@ -560,7 +700,9 @@ __device__ __forceinline__ void progress_lane(const DeviceParams& P, CarCore& s,
         const double d = dx * dx + dy * dy;
         if (i == 0 || d < best) { best = d; closest = i; }
     }
-    progress_update(P, s, steps, closest, best, times);
+    Race r; race_load(r, &s);
+    progress_update(P, r, steps, closest, best, times);
+    race_store(r, &s);
 }
 
 __global__ void ftgp_reset_kernel(DeviceParams P, const uint8_t* __restrict__ env_mask)
@@ -589,8 +731,15 @@ __global__ void ftgp_reset_kernel(DeviceParams P, const uint8_t* __restrict__ en
     for (int k = 0; k < FTGP_MAX_LAP_TIMES; ++k) P.cars[ci].times[k] = 0.0;
     progress_lane(P, s, 0, P.cars[ci].times);
     static_cast<CarCore&>(P.cars[ci]) = s;
+}
+
+// sensordata = 0 after mj_resetData (custom.py:1092): coalesced zero fill of the reset envs' scans
+__global__ void ftgp_zero_ranges_kernel(DeviceParams P, const uint8_t* __restrict__ env_mask)
+{
+    const int ci = blockIdx.x;
+    if (env_mask && !env_mask[ci / P.cars_per_env]) return;
     float* r = P.ranges + (size_t)ci * P.ranges_stride;
-    for (int j = 0; j < P.n_rays; ++j) r[j] = 0.0f;    // sensordata = 0 after mj_resetData (custom.py:1092)
+    for (int j = threadIdx.x; j < P.ranges_stride; j += blockDim.x) r[j] = 0.0f;
 }
 
 __global__ void ftgp_progress_kernel(DeviceParams P)
@@ -624,7 +773,8 @@ __global__ void ftgp_set_pose_kernel(DeviceParams P, const double* __restrict__ 
 // Metrics record (FTGP_METRIC_DOUBLES): one block, deterministic tree reduction (integers are exact in f64).
 __global__ void __launch_bounds__(256) ftgp_metrics_kernel(DeviceParams P, double* __restrict__ out)
 {
-    __shared__ double red[6][256];
+    __shared__ double red[5][256];
+    __shared__ double rmin[256], rmax[256];
     double steps = 0, laps = 0, absc = 0, fin = 0, off = 0, tmin = INFINITY, tmax = -INFINITY;
     for (int e = threadIdx.x; e < P.n_envs; e += blockDim.x) steps += (double)P.steps[e];
     for (int i = threadIdx.x; i < P.n_cars; i += blockDim.x) {
@@ -634,7 +784,6 @@ __global__ void __launch_bounds__(256) ftgp_metrics_kernel(DeviceParams P, doubl
         const int n = a.n_times < FTGP_MAX_LAP_TIMES ? a.n_times : FTGP_MAX_LAP_TIMES;
         for (int k = 0; k < n; ++k) { tmin = fmin(tmin, a.times[k]); tmax = fmax(tmax, a.times[k]); }
     }
-    __shared__ double rmin[256], rmax[256];
     red[0][threadIdx.x] = steps; red[1][threadIdx.x] = laps; red[2][threadIdx.x] = absc;
     red[3][threadIdx.x] = fin; red[4][threadIdx.x] = off; rmin[threadIdx.x] = tmin; rmax[threadIdx.x] = tmax;
     __syncthreads();

@@ -68,7 +68,7 @@ struct OracleEnv {
     float *ranges;           /* [n_cars][n_rays] */
     int64_t *steps;          /* per env */
     double wheel_load[4];
-    int lidar_mode;          /* 0 = spec f32 skip-march, 1 = f64 plain DDA (truth) */
+    int lidar_mode;          /* 0 = f32 field-accelerated march (== 2 bit for bit), 1 = binary64 plain DDA, 2 = THE SPEC: f32 plain DDA */
     int threads;
     double last_ms;
 };
@@ -244,8 +244,15 @@ static float ray_vs_cars(const OracleEnv *e, int car_index, double lcx, double l
     return best;
 }
 
-/* Specified binary32 march: variable-step DDA over the chessboard distance field. */
-static float march_f32(const OracleEnv *e, float pu, float pv, float du, float dv)
+/*
+ * THE SPECIFICATION of a ray (binary32): plain cell-by-cell DDA.  The ray p(s) = (pu + du*s, pv + dv*s) crosses the
+ * integer pixel boundary b of an axis at  sX(b) = ((float)b - pu) * (1/du)  resp.  sY(b) = ((float)b - pv) * (1/dv);
+ * from a cell the next step is the x-neighbour iff sX(next x boundary) < sY(next y boundary) (a tie steps in y);
+ * the range is the crossing time of the step that enters the first wall cell (0 if the start cell is a wall,
+ * -1 if the ray leaves the image).  Every quantity is a function of (cell, ray) alone -- nothing accumulates --
+ * so any implementation that skips wall-free cells and re-synchronises with these comparisons gives the same bits.
+ */
+static float march_plain_f32(const OracleEnv *e, float pu, float pv, float du, float dv)
 {
     const int W = e->cfg.track.width, H = e->cfg.track.height;
     int ix = (int)floorf(pu), iy = (int)floorf(pv);
@@ -253,30 +260,72 @@ static float march_f32(const OracleEnv *e, float pu, float pv, float du, float d
     const float inv_du = (du != 0.0f) ? 1.0f / du : 0.0f;
     const float inv_dv = (dv != 0.0f) ? 1.0f / dv : 0.0f;
     float s = 0.0f;
-    for (int it = 0; it < 8192; ++it) {
+    for (;;) {
+        if (wall_at(e, ix, iy)) return fabsf(s);   /* |s|: a ray that starts on a boundary can produce -0 */
+        float sX = (du != 0.0f) ? ((float)((du > 0.0f) ? ix + 1 : ix) - pu) * inv_du : INFINITY;
+        float sY = (dv != 0.0f) ? ((float)((dv > 0.0f) ? iy + 1 : iy) - pv) * inv_dv : INFINITY;
+        if (sX < sY) { s = sX; ix += (du > 0.0f) ? 1 : -1; }
+        else         { s = sY; iy += (dv > 0.0f) ? 1 : -1; }
+        if (ix < 0 || ix >= W || iy < 0 || iy >= H) return -1.0f;
+    }
+}
+
+/*
+ * The oracle's own fast path (used for the CPU baseline and the long closed-loop tests): skip over the wall-free
+ * (2k-1)^2 block of cells given by the chessboard distance field, then re-synchronise with the specification's
+ * comparisons.  tests/test_oracle_lidar.py checks it against march_plain_f32 bit for bit.
+ */
+static float march_f32(const OracleEnv *e, float pu, float pv, float du, float dv)
+{
+    const int W = e->cfg.track.width, H = e->cfg.track.height;
+    int ix = (int)floorf(pu), iy = (int)floorf(pv);
+    if (ix < 0 || ix >= W || iy < 0 || iy >= H) return -1.0f;
+    const int xnz = du != 0.0f, ynz = dv != 0.0f, xpos = du > 0.0f, ypos = dv > 0.0f;
+    const float inv_du = xnz ? 1.0f / du : 0.0f;
+    const float inv_dv = ynz ? 1.0f / dv : 0.0f;
+#define SXF(b) (((float)(b) - pu) * inv_du)
+#define SYF(b) (((float)(b) - pv) * inv_dv)
+    float s = 0.0f;
+    for (int it = 0; it < 1 << 20; ++it) {
         int k = e->field[(size_t)iy * W + ix];
-        if (k == 0) return s;
-        int bxi = (du > 0.0f) ? ix + k : ix - k + 1;
-        int byi = (dv > 0.0f) ? iy + k : iy - k + 1;
-        float sX = (du != 0.0f) ? ((float)bxi - pu) * inv_du : INFINITY;
-        float sY = (dv != 0.0f) ? ((float)byi - pv) * inv_dv : INFINITY;
+        if (k == 0) return fabsf(s);
+        int bxi = xpos ? ix + k : ix - k + 1;
+        int byi = ypos ? iy + k : iy - k + 1;
+        float sX = xnz ? SXF(bxi) : INFINITY;
+        float sY = ynz ? SYF(byi) : INFINITY;
         if (sX < sY) {
             s = sX;
-            int nix = (du > 0.0f) ? ix + k : ix - k;
-            int t = (int)floorf(fmaf(dv, s, pv));
-            int lo = iy - k + 1, hi = iy + k - 1;
-            iy = t < lo ? lo : (t > hi ? hi : t);
-            ix = nix;
+            int t = iy;
+            if (ynz) {   /* y boundaries already crossed at time s: those with sY(b) <= s */
+                t = (int)floorf(fmaf(dv, s, pv));
+                if (ypos) {
+                    int hi = iy + k - 1; if (t < iy) t = iy; if (t > hi) t = hi;
+                    if (t > iy && !(SYF(t) <= s)) t -= 1; else if (t < hi && (SYF(t + 1) <= s)) t += 1;
+                } else {
+                    int lo = iy - k + 1; if (t > iy) t = iy; if (t < lo) t = lo;
+                    if (t < iy && !(SYF(t + 1) <= s)) t += 1; else if (t > lo && (SYF(t) <= s)) t -= 1;
+                }
+            }
+            ix = xpos ? ix + k : ix - k; iy = t;
         } else {
             s = sY;
-            int niy = (dv > 0.0f) ? iy + k : iy - k;
-            int t = (int)floorf(fmaf(du, s, pu));
-            int lo = ix - k + 1, hi = ix + k - 1;
-            ix = t < lo ? lo : (t > hi ? hi : t);
-            iy = niy;
+            int t = ix;
+            if (xnz) {   /* x boundaries already crossed at time s: those with sX(b) < s (a tie steps in y first) */
+                t = (int)floorf(fmaf(du, s, pu));
+                if (xpos) {
+                    int hi = ix + k - 1; if (t < ix) t = ix; if (t > hi) t = hi;
+                    if (t > ix && !(SXF(t) < s)) t -= 1; else if (t < hi && (SXF(t + 1) < s)) t += 1;
+                } else {
+                    int lo = ix - k + 1; if (t > ix) t = ix; if (t < lo) t = lo;
+                    if (t < ix && !(SXF(t + 1) < s)) t += 1; else if (t > lo && (SXF(t) < s)) t -= 1;
+                }
+            }
+            iy = ypos ? iy + k : iy - k; ix = t;
         }
         if (ix < 0 || ix >= W || iy < 0 || iy >= H) return -1.0f;
     }
+#undef SXF
+#undef SYF
     return -1.0f;
 }
 
@@ -336,7 +385,7 @@ static void lidar_car(OracleEnv *e, int ci)
         float dv = -(dyw * isy);
         float pu = fmaf(du, -r0, u0);
         float pv = fmaf(dv, -r0, v0);
-        float r = march_f32(e, pu, pv, du, dv);
+        float r = (e->lidar_mode == 2) ? march_plain_f32(e, pu, pv, du, dv) : march_f32(e, pu, pv, du, dv);
         if (c->cars_per_env > 1) {
             float rc = ray_vs_cars(e, ci, lcx, lcy, dxw, dyw);
             if (rc < INFINITY && (r < 0.0f || rc < r)) r = rc;
