@@ -35,10 +35,13 @@ def cpu_baseline(track, n_rays, policy, cars, seed):
     ora = load_oracle()
     threads = max(1, min(os.cpu_count() or 1, int(os.environ.get("FTGP_CPU_THREADS", "16"))))
     threads = min(threads, ora.dll.oracle_max_threads()) if threads > 1 else 1
-    n_envs, steps = 64 * threads, 60
+    n_envs = 64 * threads
     with capi.Env(ora, track, n_envs=n_envs, cars_per_env=cars, n_rays=n_rays, spawn_mode=1, seed=seed) as o:
         ora.dll.oracle_set_threads(o.h, threads)
-        o.rollout(policy, 5)
+        t0 = time.perf_counter()
+        o.rollout(policy, 20)                       # calibration: size the timed sample to ~15 s of CPU work
+        rate = n_envs * 20 / (time.perf_counter() - t0)
+        steps = int(max(50, min(5000, 15.0 * rate / n_envs)))
         t0 = time.perf_counter()
         o.rollout(policy, steps)
         dt = time.perf_counter() - t0

@@ -56,8 +56,9 @@ __host__ __device__ __forceinline__ bool grid_wall(const DeviceParams& P, const 
 // K2: LiDAR
 // =============================================================================================
 // The specification of a ray is the plain cell-by-cell DDA (DESIGN.md "K2"): crossing times
-// sX(b) = ((float)b - pu) * (1/du), sY(b) = ((float)b - pv) * (1/dv); x-step iff sX < sY (a tie steps in y).
-// This march returns the same bits while skipping wall-free cells:
+// sX(b) = ((float)b - pu) * (1/du), sY(b) = ((float)b - pv) * (1/dv); x-step iff sX < sY (a tie steps in y);
+// the range is |crossing time| of the step that enters the first wall pixel, 0 in a wall, -1 off the image.
+// The march below returns the same bits while skipping wall-free cells:
 //   * an empty 8x8 block with block distance c  -> the (2c-1)^2 blocks around it hold no wall;
 //   * a pixel of a non-empty block with distance k -> the (2k-1)^2 pixels around it hold no wall;
 //   in both cases the ray jumps to the far edge of that rectangle, and the coordinate of the other axis is the
@@ -67,59 +68,117 @@ __host__ __device__ __forceinline__ bool grid_wall(const DeviceParams& P, const 
 //   images up to 8192 pixels).
 // Both axes are mirrored so that the ray always travels towards +x', +y' (x' = -x is exact in IEEE arithmetic and
 // maps cell i to ~i, block b to ~b), which removes every direction-dependent select from the loop.
-__host__ __device__ __forceinline__ float march_grid(const DeviceParams& P, const LdsView& L, float pu, float pv, float du, float dv)
+// ray_step() is one generic iteration written with selects only, so a wave can run several independent rays per
+// lane inside one wave-uniform loop (instruction-level parallelism hides the LDS latency of the lookups).
+struct Ray {
+    float pum, pvm, dum, dvm, ivx, ivy;   // mirrored origin / direction / inverse direction (0 where the direction is 0)
+    float s, result;
+    int ix, iy, mx, my;                   // mirrored cell; mirror masks (0 or -1)
+    bool active;
+};
+
+__host__ __device__ __forceinline__ void ray_init(const DeviceParams& P, Ray& r, float pu, float pv, float du, float dv, bool valid)
 {
-    const int W = P.width, H = P.height;
     const int ix0 = (int)floorf(pu), iy0 = (int)floorf(pv);
-    if (ix0 < 0 || ix0 >= W || iy0 < 0 || iy0 >= H) return -1.0f;
-    const bool xnz = du != 0.0f, ynz = dv != 0.0f;
-    const int mx = du < 0.0f ? -1 : 0, my = dv < 0.0f ? -1 : 0;
-    const float pum = mx ? -pu : pu, pvm = my ? -pv : pv;
-    const float dum = fabsf(du), dvm = fabsf(dv);
-    const float ivx = xnz ? fabsf(1.0f / du) : 0.0f, ivy = ynz ? fabsf(1.0f / dv) : 0.0f;
-    const float eps = P.snap_eps, one_m_eps = 1.0f - P.snap_eps;
-    int ix = ix0 ^ mx, iy = iy0 ^ my;      // mirrored cell indices
-    float s = 0.0f, result = -1.0f;
-    bool active = true;
-    for (int guard = 0; guard < 4096 && active; ++guard) {
-        const int tx = ix ^ mx, ty = iy ^ my;                       // true pixel
-        const int bx = tx >> 3, by = ty >> 3;
-        const int c = coarse_at(P, L, bx, by);
-        int xhi, yhi;
-        if (c == 0) {
-            const int k = fine_at(P, L, bx, by, tx, ty);
-            if (k == 0) { result = fabsf(s); active = false; break; }   // wall pixel: the crossing time that entered it
-            xhi = ix + k - 1; yhi = iy + k - 1;
-        } else {
-            xhi = (((ix >> 3) + c) << 3) - 1; yhi = (((iy >> 3) + c) << 3) - 1;
-        }
-        const float sX = xnz ? ((float)(xhi + 1) - pum) * ivx : INFINITY;
-        const float sY = ynz ? ((float)(yhi + 1) - pvm) * ivy : INFINITY;
-        const bool stepx = sX < sY;
-        s = stepx ? sX : sY;
-        const float tp = stepx ? pvm : pum, td = stepx ? dvm : dum;
-        const int cur = stepx ? iy : ix, hi = stepx ? yhi : xhi;
-        const float v = fmaf(td, s, tp);
-        const float fl = floorf(v);
-        int t = (int)fl;
-        t = t < cur ? cur : (t > hi ? hi : t);
-        const float frac = v - fl;
-        if (!(frac >= eps && frac <= one_m_eps)) {
-            // within eps of a boundary: ask the specification
-            const float tinv = stepx ? ivy : ivx;
-            const float Sa = ((float)t - tp) * tinv, Sb = ((float)(t + 1) - tp) * tinv;
-            const bool ca = stepx ? (Sa <= s) : (Sa < s), cb = stepx ? (Sb <= s) : (Sb < s);
-            const bool dec = (t > cur) & !ca;
-            const bool inc = !dec & (t < hi) & cb;
-            t += (inc ? 1 : 0) - (dec ? 1 : 0);
-        }
-        t = (stepx ? ynz : xnz) ? t : cur;
-        ix = stepx ? xhi + 1 : t;
-        iy = stepx ? t : yhi + 1;
-        const int nx = ix ^ mx, ny = iy ^ my;
-        active = nx >= 0 && nx < W && ny >= 0 && ny < H;           // leaving the image: -1
+    r.mx = du < 0.0f ? -1 : 0; r.my = dv < 0.0f ? -1 : 0;
+    r.pum = r.mx ? -pu : pu; r.pvm = r.my ? -pv : pv;
+    r.dum = fabsf(du); r.dvm = fabsf(dv);
+    r.ivx = (du != 0.0f) ? fabsf(1.0f / du) : 0.0f;
+    r.ivy = (dv != 0.0f) ? fabsf(1.0f / dv) : 0.0f;
+    r.s = 0.0f; r.result = -1.0f;
+    const bool inside = ix0 >= 0 && ix0 < P.width && iy0 >= 0 && iy0 < P.height;
+    r.active = valid && inside;
+    r.ix = (inside ? ix0 : 0) ^ r.mx; r.iy = (inside ? iy0 : 0) ^ r.my;
+}
+
+// Lookup of one generic iteration, split so that a wave can put the LDS reads of several rays in flight together:
+//   stage 1: the rank word of the ray's block (non-empty bit + running count)            -> 1 LDS read
+//   stage 2: EITHER the block-distance nibble (empty block) OR the pixel-distance nibble  -> 1 LDS read
+struct Probe { int addr2, shift2; bool nonempty; };
+
+__host__ __device__ __forceinline__ int ray_rank_addr(const DeviceParams& P, const Ray& r)
+{
+    const int tx = r.ix ^ r.mx, ty = r.iy ^ r.my;                  // true pixel (always inside the image)
+    return (ty >> 3) * P.nwpr + (tx >> 8);
+}
+__host__ __device__ __forceinline__ Probe ray_probe(const DeviceParams& P, const Ray& r, uint2 rk)
+{
+    const int tx = r.ix ^ r.mx, ty = r.iy ^ r.my;
+    const int bx = tx >> 3, by = ty >> 3;
+    Probe p;
+    p.nonempty = (rk.x >> (bx & 31)) & 1u;
+    const int idx = (int)rk.y + __builtin_popcount(rk.x & ((1u << (bx & 31)) - 1u));
+    const int n = ((ty & 7) << 3) | (tx & 7);
+    const int q = by * P.nbx + bx;
+    // byte offsets relative to the start of the fine table / coarse table (both live in one LDS allocation)
+    p.addr2 = p.nonempty ? (P.off_fine + (idx << 5) + (n >> 1)) : (P.off_coarse + (q >> 1));
+    p.shift2 = ((p.nonempty ? n : q) & 1) << 2;
+    return p;
+}
+
+// returns true when the landing point was too close to a pixel boundary to trust floor(): the caller then runs ray_fix()
+__host__ __device__ __forceinline__ bool ray_step(const DeviceParams& P, Ray& r, const Probe& pb, unsigned byte2,
+                                                  int& t_out, int& cur_out, int& hi_out, bool& stepx_out, int& xhi_out, int& yhi_out)
+{
+    const int k = (int)(byte2 >> pb.shift2) & 15;                  // pixel distance (non-empty block) or block distance (empty block)
+    const bool hit = r.active & pb.nonempty & (k == 0);
+    r.result = hit ? fabsf(r.s) : r.result;
+    r.active = r.active & !hit;
+    const int xhi = pb.nonempty ? r.ix + k - 1 : (((r.ix >> 3) + k) << 3) - 1;
+    const int yhi = pb.nonempty ? r.iy + k - 1 : (((r.iy >> 3) + k) << 3) - 1;
+    const float sX = (r.dum != 0.0f) ? ((float)(xhi + 1) - r.pum) * r.ivx : INFINITY;
+    const float sY = (r.dvm != 0.0f) ? ((float)(yhi + 1) - r.pvm) * r.ivy : INFINITY;
+    const bool stepx = sX < sY;
+    const float s = stepx ? sX : sY;
+    r.s = r.active ? s : r.s;
+    const float tp = stepx ? r.pvm : r.pum, td = stepx ? r.dvm : r.dum;
+    const int cur = stepx ? r.iy : r.ix, hi = stepx ? yhi : xhi;
+    const float v = fmaf(td, s, tp);
+    const float fl = floorf(v);
+    int t = (int)fl;
+    t = t < cur ? cur : (t > hi ? hi : t);
+    const float frac = v - fl;
+    t_out = t; cur_out = cur; hi_out = hi; stepx_out = stepx; xhi_out = xhi; yhi_out = yhi;
+    return r.active & !(frac >= P.snap_eps && frac <= 1.0f - P.snap_eps);
+}
+
+// the specification's comparisons for a landing point within snap_eps of a boundary
+__host__ __device__ __forceinline__ int ray_fix(const Ray& r, int t, int cur, int hi, bool stepx)
+{
+    const float tp = stepx ? r.pvm : r.pum, tinv = stepx ? r.ivy : r.ivx;
+    const float Sa = ((float)t - tp) * tinv, Sb = ((float)(t + 1) - tp) * tinv;
+    const bool ca = stepx ? (Sa <= r.s) : (Sa < r.s), cb = stepx ? (Sb <= r.s) : (Sb < r.s);
+    const bool dec = (t > cur) & !ca;
+    const bool inc = !dec & (t < hi) & cb;
+    return t + (inc ? 1 : 0) - (dec ? 1 : 0);
+}
+
+__host__ __device__ __forceinline__ void ray_commit(const DeviceParams& P, Ray& r, int t, int cur, bool stepx, int xhi, int yhi)
+{
+    const bool tnz = stepx ? (r.dvm != 0.0f) : (r.dum != 0.0f);
+    t = tnz ? t : cur;
+    const int nix = stepx ? xhi + 1 : t, niy = stepx ? t : yhi + 1;
+    const int nx = nix ^ r.mx, ny = niy ^ r.my;
+    const bool inside = ((unsigned)nx < (unsigned)P.width) & ((unsigned)ny < (unsigned)P.height);
+    const bool go = r.active & inside;
+    r.ix = go ? nix : r.ix; r.iy = go ? niy : r.iy;               // an inactive ray keeps its last in-image cell (lookups stay in range)
+    r.active = go;                                                 // leaving the image: result stays -1
+}
+
+// single ray (host harness, contact-free uses); lds = base of the staged LDS image
+__host__ __device__ __forceinline__ float march_grid(const DeviceParams& P, const unsigned char* lds, float pu, float pv, float du, float dv)
+{
+    const uint2* rank = reinterpret_cast<const uint2*>(lds + P.off_rank);
+    Ray r; ray_init(P, r, pu, pv, du, dv, true);
+    for (int guard = 0; guard < 8192 && r.active; ++guard) {
+        const uint2 rk = rank[ray_rank_addr(P, r)];
+        const Probe pb = ray_probe(P, r, rk);
+        int t, cur, hi, xhi, yhi; bool stepx;
+        const bool near = ray_step(P, r, pb, lds[pb.addr2], t, cur, hi, stepx, xhi, yhi);
+        if (near) t = ray_fix(r, t, cur, hi, stepx);
+        ray_commit(P, r, t, cur, stepx, xhi, yhi);
     }
-    return result;
+    return r.result;
 }
 
 // Ray against another car: chassis box (slab test) and LiDAR puck (circle), binary32.
@@ -167,6 +226,10 @@ __device__ __forceinline__ float ray_vs_car(const FtgpVehicle& v, const CarCore*
 // Full sweep of one car by one wave.  Rangefinder geometry: template/mushr.em.xml:98-117 -- ray j leaves
 // the ring at centre - 0.03*dir_j, dir_j = R(yaw) * (sin phi_j, -cos phi_j); j = 0 is the rear, CCW.
 // Values replace data.sensordata[vehicle_state.sensors] (custom.py:1395).
+// Each lane marches FTGP_RPL rays at once (rays j, j + 64, ... of a 64*RPL group) in one wave-uniform loop.
+#ifndef FTGP_RPL
+#define FTGP_RPL 1
+#endif
 template <bool MULTI>
 __device__ __forceinline__ void lidar_sweep(const DeviceParams& P, const LdsView& L, const CarCore* st, float* __restrict__ out_global,
                                             float* __restrict__ out_lds, const CarCore* env_cars, int my_slot)
@@ -183,28 +246,66 @@ __device__ __forceinline__ void lidar_sweep(const DeviceParams& P, const LdsView
     const float r0 = (float)v.lidar_ring_radius;
     const int R = P.n_rays;
     const int lane = lane_id();
-    for (int base = 0; base < R; base += FTGP_WAVE) {
-        const int j = base + lane;
-        if (j < R) {
-            const float bx = L.ray_bx[j], by = L.ray_by[j];
-            const float dxw = fmaf(chf, bx, -(shf * by));
-            const float dyw = fmaf(shf, bx, chf * by);
-            const float du = dxw * isx;
-            const float dv = -(dyw * isy);
+    const unsigned char* lds_base = reinterpret_cast<const unsigned char*>(L.veh) - P.off_veh;
+    const uint2* rank = L.rank;
+    for (int base = 0; base < R; base += FTGP_WAVE * FTGP_RPL) {
+        Ray ray[FTGP_RPL];
+        float dxw[FTGP_RPL], dyw[FTGP_RPL];
+        #pragma unroll
+        for (int q = 0; q < FTGP_RPL; ++q) {
+            const int j = base + q * FTGP_WAVE + lane;
+            const bool valid = j < R;
+            const int jj = valid ? j : 0;
+            const float bx = L.ray_bx[jj], by = L.ray_by[jj];
+            dxw[q] = fmaf(chf, bx, -(shf * by));
+            dyw[q] = fmaf(shf, bx, chf * by);
+            const float du = dxw[q] * isx;
+            const float dv = -(dyw[q] * isy);
             const float pu = fmaf(du, -r0, u0);
             const float pv = fmaf(dv, -r0, v0);
-            float r = march_grid(P, L, pu, pv, du, dv);
-            if (MULTI) {
-                for (int k = 0; k < P.cars_per_env; ++k) {
-                    if (k == my_slot) continue;
-                    const float rc = ray_vs_car(v, env_cars + k, lcx, lcy, dxw, dyw);
-                    if (rc < INFINITY && (r < 0.0f || rc < r)) r = rc;
-                }
+            ray_init(P, ray[q], pu, pv, du, dv, valid);
+        }
+        for (int guard = 0; guard < 8192; ++guard) {
+            bool any_active = false;
+            #pragma unroll
+            for (int q = 0; q < FTGP_RPL; ++q) any_active |= ray[q].active;
+            if (!__any(any_active)) break;
+            int t[FTGP_RPL], cur[FTGP_RPL], hi[FTGP_RPL], xhi[FTGP_RPL], yhi[FTGP_RPL]; bool stepx[FTGP_RPL], near[FTGP_RPL];
+            uint2 rk[FTGP_RPL]; Probe pb[FTGP_RPL]; unsigned b2[FTGP_RPL];
+            #pragma unroll
+            for (int q = 0; q < FTGP_RPL; ++q) rk[q] = rank[ray_rank_addr(P, ray[q])];          // stage 1: all rays' rank words in flight
+            #pragma unroll
+            for (int q = 0; q < FTGP_RPL; ++q) { pb[q] = ray_probe(P, ray[q], rk[q]); b2[q] = lds_base[pb[q].addr2]; }   // stage 2
+            bool any_near = false;
+            #pragma unroll
+            for (int q = 0; q < FTGP_RPL; ++q) {
+                near[q] = ray_step(P, ray[q], pb[q], b2[q], t[q], cur[q], hi[q], stepx[q], xhi[q], yhi[q]);
+                any_near |= near[q];
             }
-            out_global[j] = r;
-            if (out_lds) {      // the on-device driver only reads ranges[0] and ranges[eighth : n - eighth]
-                if (j == 0) out_lds[0] = r;
-                if (j >= P.eighth && j < R - P.eighth) out_lds[1 + j - P.eighth] = r;
+            if (__any(any_near)) {
+                #pragma unroll
+                for (int q = 0; q < FTGP_RPL; ++q) { const int tf = ray_fix(ray[q], t[q], cur[q], hi[q], stepx[q]); t[q] = near[q] ? tf : t[q]; }
+            }
+            #pragma unroll
+            for (int q = 0; q < FTGP_RPL; ++q) ray_commit(P, ray[q], t[q], cur[q], stepx[q], xhi[q], yhi[q]);
+        }
+        #pragma unroll
+        for (int q = 0; q < FTGP_RPL; ++q) {
+            const int j = base + q * FTGP_WAVE + lane;
+            if (j < R) {
+                float r = ray[q].result;
+                if (MULTI) {
+                    for (int k = 0; k < P.cars_per_env; ++k) {
+                        if (k == my_slot) continue;
+                        const float rc = ray_vs_car(v, env_cars + k, lcx, lcy, dxw[q], dyw[q]);
+                        if (rc < INFINITY && (r < 0.0f || rc < r)) r = rc;
+                    }
+                }
+                out_global[j] = r;
+                if (out_lds) {      // the on-device driver only reads ranges[0] and ranges[eighth : n - eighth]
+                    if (j == 0) out_lds[0] = r;
+                    if (j >= P.eighth && j < R - P.eighth) out_lds[1 + j - P.eighth] = r;
+                }
             }
         }
     }

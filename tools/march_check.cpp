@@ -37,7 +37,13 @@ int main(int argc, char** argv)
     HostGrid g; build_grid(t, g);
     DeviceParams P{}; P.width = t.width; P.height = t.height; P.nbx = g.nbx; P.nby = g.nby; P.nwpr = g.nwpr; P.n_fine = g.n_fine;
     P.snap_eps = 1.0f / 512.0f;
-    LdsView L{}; L.fine = g.fine.data(); L.rank = g.rank.data(); L.coarse = g.coarse.data();
+    P.n_rays = 8; P.eighth = 1; P.scan_floats = 8; P.ray_floats = 8;
+    lds_layout(P, 1);
+    std::vector<unsigned char> img((size_t)P.lds_bytes, 0);
+    memcpy(img.data() + P.off_fine, g.fine.data(), g.fine.size());
+    memcpy(img.data() + P.off_rank, g.rank.data(), g.rank.size() * sizeof(uint2));
+    memcpy(img.data() + P.off_coarse, g.coarse.data(), g.coarse.size());
+    LdsView L{}; L.fine = img.data() + P.off_fine; L.rank = reinterpret_cast<const uint2*>(img.data() + P.off_rank); L.coarse = img.data() + P.off_coarse;
     long gw_bad = 0;
     for (int y = 0; y < t.height; ++y)
         for (int x = 0; x < t.width; ++x)
@@ -57,7 +63,7 @@ int main(int argc, char** argv)
         float du = (float)(cos(a) * scale), dv = (float)(sin(a) * scale);
         if (kind == 3 || kind == 4) { if (fabsf(du) < 1e-3f) du = 0.0f; if (fabsf(dv) < 1e-3f) dv = 0.0f; }
         if (kind == 2 && (i & 8)) { du = (float)(int)(du); dv = (float)(int)dv; if (du == 0 && dv == 0) du = 1; }
-        const float a_ = march_grid(P, L, pu, pv, du, dv), b_ = plain(t, pu, pv, du, dv);
+        const float a_ = march_grid(P, img.data(), pu, pv, du, dv), b_ = plain(t, pu, pv, du, dv);
         hits += b_ >= 0;
         if (memcmp(&a_, &b_, 4) != 0) {
             if (bad < 10) printf("MISMATCH kind %d pu %.9g pv %.9g du %.9g dv %.9g : grid %.9g plain %.9g\n", kind, pu, pv, du, dv, a_, b_);
