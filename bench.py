@@ -80,8 +80,9 @@ def main():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
     track = load_track(args.track)
     seed = 1234
+    # rank r owns envs [r * envs_per_gpu, (r + 1) * envs_per_gpu) of one world-sized batch (BASELINE.json configs[3] at N = 8)
     env = capi.Env(lib, track, n_envs=args.envs_per_gpu, cars_per_env=args.cars, n_rays=args.rays, spawn_mode=1,
-                   seed=seed + 1000003 * rank, device_id=local_rank)
+                   seed=seed, device_id=local_rank, env_base=rank * args.envs_per_gpu)
     if world > 1:
         import torch
         uid = [capi.comm_unique_id(lib) if rank == 0 else None]

@@ -58,7 +58,7 @@ class FtgpVehicle(C.Structure):
 class FtgpConfig(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("n_envs", C.c_int32), ("cars_per_env", C.c_int32),
                 ("n_rays", C.c_int32), ("lap_target", C.c_int32), ("device_id", C.c_int32),
-                ("spawn_mode", C.c_int32), ("reserved0", C.c_int32), ("seed", C.c_uint64),
+                ("spawn_mode", C.c_int32), ("env_base", C.c_int32), ("seed", C.c_uint64),
                 ("dt", C.c_double), ("track", FtgpTrack), ("vehicle", FtgpVehicle)]
 
 
@@ -167,7 +167,7 @@ class Env:
 
     def __init__(self, lib: CLib, track: Track, n_envs: int = 1, cars_per_env: int = 1, n_rays: int = 90,
                  lap_target: int = 10, dt: float = 0.004, spawn_mode: int = 0, seed: int = 1234,
-                 device_id: int = 0, vehicle: Optional[FtgpVehicle] = None):
+                 device_id: int = 0, vehicle: Optional[FtgpVehicle] = None, env_base: int = 0):
         self.lib, self.track = lib, track
         self.n_envs, self.cars_per_env, self.n_rays = int(n_envs), int(cars_per_env), int(n_rays)
         self.n_cars = self.n_envs * self.cars_per_env
@@ -176,6 +176,8 @@ class Env:
         cfg.abi_version = ABI_VERSION
         cfg.n_envs, cfg.cars_per_env, cfg.n_rays = self.n_envs, self.cars_per_env, self.n_rays
         cfg.lap_target, cfg.device_id, cfg.spawn_mode, cfg.seed, cfg.dt = lap_target, device_id, spawn_mode, seed, dt
+        cfg.env_base = env_base
+        self.env_base = int(env_base)
         self._bits = np.ascontiguousarray(track.bits, dtype=np.uint32)
         self._path = np.ascontiguousarray(track.path, dtype=np.float64)
         assert self._path.shape == (PATH_POINTS, 2)

@@ -281,6 +281,7 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
     const FtgpTrack& t = cfg->track;
     if (t.width < 1 || t.height < 1 || !t.bits || !t.path || t.words_per_row < (t.width + 31) / 32)
         return fail(FTGP_ERR_ARG, "bad track%s");
+    if (cfg->env_base < 0) return fail(FTGP_ERR_ARG, "env_base < 0%s");
     if (!(cfg->dt > 0.0) || !(t.px_size_x > 0.0) || !(t.px_size_y > 0.0)) return fail(FTGP_ERR_ARG, "bad dt / pixel size%s");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
@@ -308,7 +309,7 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
 
     DeviceParams& P = e->P;
     P.n_envs = cfg->n_envs; P.cars_per_env = cfg->cars_per_env; P.n_cars = cfg->n_envs * cfg->cars_per_env;
-    P.n_rays = cfg->n_rays; P.lap_target = cfg->lap_target; P.spawn_mode = cfg->spawn_mode;
+    P.n_rays = cfg->n_rays; P.lap_target = cfg->lap_target; P.spawn_mode = cfg->spawn_mode; P.env_base = cfg->env_base;
     P.ranges_stride = (cfg->n_rays + 63) & ~63;      // rows start on 256-B boundaries: every pass is one aligned store
     P.seed = cfg->seed; P.dt = cfg->dt;
     P.width = t.width; P.height = t.height; P.words_per_row = t.words_per_row;

@@ -30,7 +30,7 @@ static_assert(sizeof(CarState) == 320, "CarState layout");
 struct DeviceParams {
     // sizes
     int32_t n_envs, cars_per_env, n_cars, n_rays;
-    int32_t lap_target, spawn_mode, ranges_stride, pad0;
+    int32_t lap_target, spawn_mode, ranges_stride, env_base;
     uint64_t seed;
     double dt;
     // track

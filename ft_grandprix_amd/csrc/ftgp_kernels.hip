@@ -656,7 +656,7 @@ __device__ __forceinline__ void policy_apply(const DeviceParams& P, int policy, 
     case FTGP_POLICY_NIDC: policy_disparity(P, scan, c, false); break;
     case FTGP_POLICY_FAST: policy_disparity(P, scan, c, true); break;
     case FTGP_POLICY_RANDOM: {
-        uint64_t h = splitmix64(P.seed + (uint64_t)ci * 0x9E3779B97F4A7C15ull);
+        uint64_t h = splitmix64(P.seed + (uint64_t)((long)P.env_base * P.cars_per_env + ci) * 0x9E3779B97F4A7C15ull);
         h = splitmix64(h ^ (uint64_t)steps);
         c.speed = 3.0 * u01(h);
         c.steer = 2.0 * u01(splitmix64(h)) - 1.0;
@@ -814,13 +814,13 @@ __global__ void ftgp_reset_kernel(DeviceParams P, const uint8_t* __restrict__ en
     if (env_mask && !env_mask[env]) return;
     CarCore s;
     memset(&s, 0, sizeof s);
-    const int p = (P.spawn_mode == 0) ? (car + 5) * 2 : (10 + 7 * env + 2 * car) % 98;   // custom.py:1112
+    const int p = (P.spawn_mode == 0) ? (car + 5) * 2 : (int)((10 + 7 * (long)(P.env_base + env) + 2 * car) % 98);   // custom.py:1112
     s.offset = p;
     s.good_start = 1;
     s.x = P.spawn[4 * p]; s.y = P.spawn[4 * p + 1];
     double qw = P.spawn[4 * p + 2], qz = P.spawn[4 * p + 3];
     if (P.spawn_mode == 1) {
-        const uint64_t h = splitmix64(P.seed ^ (0xA0761D6478BD642Full + (uint64_t)ci));
+        const uint64_t h = splitmix64(P.seed ^ (0xA0761D6478BD642Full + (uint64_t)((long)P.env_base * P.cars_per_env + ci)));
         const double j = 0.2 * u01(h) - 0.1;
         const double cj = spec_cos(0.5 * j), sj = spec_sin(0.5 * j);
         const double nw = qw * cj - qz * sj, nz = qz * cj + qw * sj;

@@ -98,8 +98,9 @@ typedef struct FtgpConfig {
     int32_t lap_target;             /* custom.py:961, used custom.py:1367 */
     int32_t device_id;              /* HIP device ordinal */
     int32_t spawn_mode;             /* 0 = reference: car i at path[(i+5)*2] (custom.py:1112,1232-1245);
-                                       1 = benchmark spread: env e, car i at path[(10 + 7*e + 2*i) % 98] with seeded yaw jitter */
-    int32_t reserved0;
+                                       1 = benchmark spread: global env e, car i at path[(10 + 7*e + 2*i) % 98] with seeded yaw jitter */
+    int32_t env_base;               /* global index of this handle's env 0: a shard [env_base, env_base + n_envs) of a larger batch spawns,
+                                       jitters and draws random controls exactly like the same slice of the monolithic batch */
     uint64_t seed;                  /* spawn jitter and FTGP_POLICY_RANDOM */
     double dt;                      /* 0.004 (mushr.em.xml:30) */
     FtgpTrack track;

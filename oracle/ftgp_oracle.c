@@ -645,7 +645,7 @@ static void policy_car(OracleEnv *e, int policy, int ci)
     case FTGP_POLICY_NIDC: policy_disparity(e, r, a, 0, &a->u_speed, &a->u_steer); break;
     case FTGP_POLICY_FAST: policy_disparity(e, r, a, 1, &a->u_speed, &a->u_steer); break;
     case FTGP_POLICY_RANDOM: {
-        uint64_t h = splitmix64(e->cfg.seed + (uint64_t)ci * 0x9E3779B97F4A7C15ull);
+        uint64_t h = splitmix64(e->cfg.seed + (uint64_t)((long)e->cfg.env_base * e->cfg.cars_per_env + ci) * 0x9E3779B97F4A7C15ull);
         h = splitmix64(h ^ (uint64_t)e->steps[env]);
         a->u_speed = 3.0 * u01(h);
         a->u_steer = 2.0 * u01(splitmix64(h)) - 1.0;
@@ -670,7 +670,7 @@ int oracle_policy_eval1(int policy, int n_rays, const float *ranges, double *las
 static int spawn_index(const OracleEnv *e, int env, int car)
 {
     if (e->cfg.spawn_mode == 0) return (car + 5) * 2;             /* custom.py:1112 */
-    return (10 + 7 * env + 2 * car) % 98;
+    return (int)((10 + 7 * (long)(e->cfg.env_base + env) + 2 * car) % 98);
 }
 
 static void reset_car(OracleEnv *e, int ci)
@@ -686,7 +686,7 @@ static void reset_car(OracleEnv *e, int ci)
     double qw = e->spawn[p][2], qz = e->spawn[p][3];
     if (e->cfg.spawn_mode == 1) {
         /* yaw jitter U(-0.1, 0.1) rad, keyed (seed, car index) */
-        uint64_t h = splitmix64(e->cfg.seed ^ (0xA0761D6478BD642Full + (uint64_t)ci));
+        uint64_t h = splitmix64(e->cfg.seed ^ (0xA0761D6478BD642Full + (uint64_t)((long)e->cfg.env_base * cpe + ci)));
         double j = 0.2 * u01(h) - 0.1;
         double cj = spec_cos(0.5 * j), sj = spec_sin(0.5 * j);
         double nw = qw * cj - qz * sj, nz = qz * cj + qw * sj;

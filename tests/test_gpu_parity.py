@@ -222,3 +222,36 @@ def test_headline_size_properties_and_oracle_prefix(product, oracle):
         np.testing.assert_array_equal(g.progress()[:32], o.progress())
         np.testing.assert_allclose(g.pose()[:32], o.pose(), rtol=0, atol=TOL)
         assert g.last_kernel_ms() > 0
+
+
+def test_gpu_shards_reproduce_the_monolithic_batch(product):
+    """a shard [env_base, env_base + n) must equal the same slice of the whole batch (two handles, one GPU)."""
+    from ft_grandprix_amd import dist as ftdist
+    t = load_track("track")
+    kw = dict(n_rays=1080, spawn_mode=1, seed=1234)
+    with capi.Env(product, t, n_envs=96, **kw) as mono:
+        mono.rollout("random", 150)
+        recs = []
+        for rank in range(2):
+            with ftdist.make_shard(product, t, 96, rank, 2, **kw) as sh:
+                start, count = ftdist.shard_range(96, rank, 2)
+                sh.rollout("random", 150)
+                np.testing.assert_array_equal(sh.lidar(), mono.lidar()[start:start + count])
+                np.testing.assert_array_equal(sh.pose(), mono.pose()[start:start + count])
+                recs.append(sh.metrics_local())
+        tot, ref = ftdist.reduce_metrics(np.stack(recs)), ftdist.reduce_metrics(mono.metrics_local()[None])
+        assert tot == {**ref, "ranks": 2}
+
+
+def test_rccl_communicator_single_rank(product):
+    """C1 through the real RCCL entry points (ncclGetUniqueId / ncclCommInitRank / ncclAllGather) with world_size 1."""
+    t = load_track("circle")
+    with capi.Env(product, t, n_envs=8, n_rays=36, spawn_mode=1) as g:
+        uid = capi.comm_unique_id(product)
+        assert len(uid) == 128 and any(uid)
+        g.comm_init(uid, 0, 1)
+        g.rollout("nidc", 40)
+        rec = g.metrics_allgather()
+        assert rec.shape == (1, capi.METRIC_DOUBLES)
+        np.testing.assert_array_equal(rec[0], g.metrics_local())
+        assert rec[0][0] == 8 * 40 and rec[0][1] == 8

@@ -1,0 +1,92 @@
+"""N > 1 layout on CPU: shards reproduce the monolithic batch; the metrics all-gather over gloo (world_size 2)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from ft_grandprix_amd import capi, dist as ftdist
+from ft_grandprix_amd.track import load_track
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_range_is_a_partition():
+    for total, world in ((4096, 8), (32768, 8), (10, 3), (7, 8)):
+        spans = [ftdist.shard_range(total, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and sum(c for _, c in spans) == total
+        for (s0, c0), (s1, _) in zip(spans, spans[1:]):
+            assert s0 + c0 == s1
+    with pytest.raises(ValueError):
+        ftdist.shard_range(8, 2, 2)
+
+
+@pytest.mark.parametrize("policy", ["fast", "random"])
+def test_shards_reproduce_the_monolithic_batch(oracle, policy):
+    t = load_track("circle")
+    kw = dict(n_rays=90, spawn_mode=1, seed=77, lap_target=2)
+    with capi.Env(oracle, t, n_envs=24, **kw) as mono:
+        mono.rollout(policy, 120)
+        recs = []
+        for rank in range(3):
+            with ftdist.make_shard(oracle, t, 24, rank, 3, **kw) as sh:
+                start, count = ftdist.shard_range(24, rank, 3)
+                assert sh.env_base == start and sh.n_envs == count
+                sh.rollout(policy, 120)
+                np.testing.assert_array_equal(sh.lidar(), mono.lidar()[start:start + count])
+                np.testing.assert_array_equal(sh.pose(), mono.pose()[start:start + count])
+                np.testing.assert_array_equal(sh.progress(), mono.progress()[start:start + count])
+                recs.append(sh.metrics_local())
+        tot, ref = ftdist.reduce_metrics(np.stack(recs)), ftdist.reduce_metrics(mono.metrics_local()[None])
+        for k in capi.METRIC_FIELDS:
+            assert tot[k] == ref[k], k
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _rank_main(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from tests.helpers import load_oracle
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        ora = load_oracle()
+        t = load_track("circle")
+        with ftdist.make_shard(ora, t, 12, rank, world, n_rays=36, spawn_mode=1, seed=5, lap_target=1) as sh:
+            sh.rollout("fast", 150)
+            recs = ftdist.gather_metrics(sh, ftdist.GlooGather())       # the N > 1 exchange, over gloo
+            dist.barrier()
+            q.put((rank, recs, sh.metrics_local()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_size_2_gloo_metrics_allgather(oracle):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs: p.start()
+    out = sorted((q.get(timeout=120) for _ in procs), key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # every rank holds every rank's record, in rank order
+    np.testing.assert_array_equal(out[0][1], out[1][1])
+    for r in range(2):
+        np.testing.assert_array_equal(out[0][1][r], out[r][2])
+    t = load_track("circle")
+    with capi.Env(oracle, t, n_envs=12, n_rays=36, spawn_mode=1, seed=5, lap_target=1) as mono:
+        mono.rollout("fast", 150)
+        ref = ftdist.reduce_metrics(mono.metrics_local()[None])
+    tot = ftdist.reduce_metrics(out[0][1])
+    assert tot["ranks"] == 2
+    for k in capi.METRIC_FIELDS:
+        assert tot[k] == ref[k], k

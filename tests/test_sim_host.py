@@ -1,0 +1,77 @@
+"""Host-side driver surface (ft_grandprix_amd.sim) on CPU, with the oracle standing in for the device library.
+
+When the reference checkout is present (/root/reference, never on the GPU box) its OWN nidc / fast / template
+drivers are loaded unmodified through roster strings and driven for a few hundred steps; the closed-loop result must
+agree with the oracle's restated drivers (K5) run on the same worlds."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from ft_grandprix_amd import capi
+from ft_grandprix_amd.sim import Simulator, LobotomyDriver, resolve_driver_path, VehicleStateSnapshot
+from ft_grandprix_amd.track import load_track
+
+REF = "/root/reference"
+have_ref = os.path.isdir(os.path.join(REF, "ft_grandprix"))
+
+
+def test_roster_path_resolution_matches_reference_rules():
+    assert resolve_driver_path("file://ft_grandprix/nidc.py") == "ft_grandprix.nidc"      # custom.py:1097-1098
+    assert resolve_driver_path("ft_grandprix.fast") == "ft_grandprix.fast"                # custom.py:1099-1102
+    assert resolve_driver_path("http://x/y.py") is None                                   # custom.py:1103-1104
+
+
+def test_import_failure_falls_back_to_null_driver_and_arity_is_sniffed(oracle):
+    import types
+
+    class V2:
+        def process_lidar(self, ranges, state):
+            assert isinstance(state, VehicleStateSnapshot) and len(state.velocity) == 3
+            return 1.0, 0.1
+    m = types.ModuleType("ftgp_v2_driver"); m.Driver = V2; sys.modules["ftgp_v2_driver"] = m
+    sim = Simulator(load_track("small-circle"), [{"driver": "ftgp_v2_driver", "name": "a"}, {"driver": "does.not.exist", "name": "b"}],
+                    n_envs=2, n_rays=36, lib=oracle)
+    assert [vs.v2 for vs in sim.vehicle_states] == [True, False, True, False]
+    assert isinstance(sim.vehicle_states[1].driver, LobotomyDriver)
+    assert [vs.offset for vs in sim.vehicle_states[:2]] == [10, 12]                       # (i + 5) * 2, custom.py:1112
+    sim.drive(20)
+    c = sim.env.ctrl()
+    np.testing.assert_array_equal(c[0], [1.0, 0.1]); np.testing.assert_array_equal(c[1], [0.0, 0.0])
+    snap = sim.snapshots()[0]
+    assert snap.time == 20 / 0.004                                                       # steps / timestep (sic), custom.py:1397
+    assert sim.ranking()[0] in (0, 2)
+    sim.close()
+
+
+@pytest.mark.skipif(not have_ref, reason="reference checkout not present")
+@pytest.mark.parametrize("name,policy", [("ft_grandprix.nidc", "nidc"), ("file://ft_grandprix/fast.py", "fast")])
+def test_unmodified_reference_drivers_close_the_loop(oracle, name, policy):
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    t = load_track("track")
+    cars = [{"driver": name, "name": "ref"}]
+    sim = Simulator(t, cars, n_envs=3, n_rays=90, lib=oracle, spawn_mode=1, seed=9)
+    assert type(sim.vehicle_states[0].driver).__module__.startswith("ft_grandprix.")
+    with capi.Env(oracle, t, n_envs=3, n_rays=90, spawn_mode=1, seed=9) as dev:
+        with np.errstate(all="ignore"):
+            sim.drive(300)
+        dev.rollout(policy, 300)
+        # the Python drivers see float64 copies of the f32 scan; the restated K5 agrees to rounding, so the closed loops stay together
+        np.testing.assert_array_equal(sim.env.progress(), dev.progress())
+        np.testing.assert_allclose(sim.env.pose(), dev.pose(), rtol=0, atol=1e-6)
+        np.testing.assert_allclose(sim.env.lidar(), dev.lidar(), rtol=0, atol=1e-4)
+    sim.close()
+
+
+@pytest.mark.skipif(not have_ref, reason="reference checkout not present")
+def test_reference_template_driver_runs_unmodified(oracle):
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    sim = Simulator(load_track("small-circle"), [{"driver": "drivers.template", "name": "t"}], n_envs=1, n_rays=36, lib=oracle)
+    assert sim.vehicle_states[0].v2
+    sim.drive(50)
+    np.testing.assert_array_equal(sim.env.ctrl(), 0.0)
+    np.testing.assert_array_equal(sim.env.steps(), [50])
+    sim.close()
