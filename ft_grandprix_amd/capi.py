@@ -67,7 +67,7 @@ API_SYMBOLS = (
     "default_vehicle", "last_error", "device_count", "create", "destroy", "reset", "set_ctrl", "step",
     "rollout", "get_lidar", "get_snapshot", "get_pose", "get_progress", "get_lap_times", "get_ctrl",
     "get_steps", "set_pose", "policy_eval", "eval_progress", "metrics_local", "comm_unique_id", "comm_init", "metrics_allgather",
-    "last_kernel_ms", "kernel_name",
+    "last_kernel_ms", "kernel_name", "fakelidar",
 )
 
 
@@ -125,10 +125,13 @@ class CLib:
             "comm_unique_id": (i32, [dp]),
             "comm_init": (i32, [vp, dp, i32, i32]),
             "metrics_allgather": (i32, [vp, dp]),
+            "fakelidar": (i32, [i32, dp, i32, i32, i32, dp, i32, dp, dp, C.c_double, dp, dp]),
             "last_kernel_ms": (i32, [vp, C.POINTER(C.c_float)]),
             "kernel_name": (C.c_char_p, [vp]),
         }
         for name, (res, args) in sigs.items():
+            if name == "fakelidar" and self.prefix != "ftgp_":
+                continue        # the oracle's single-origin form is typed by tests/helpers.py
             if self.has(name):
                 f = self.fn(name)
                 f.restype, f.argtypes = res, args
@@ -306,6 +309,26 @@ class Env:
     def kernel_name(self) -> str:
         s = self.lib.fn("kernel_name")(self.h)
         return s.decode() if s else ""
+
+
+def fakelidar(lib: CLib, dt: np.ndarray, origins: np.ndarray, cosines: np.ndarray, sines: np.ndarray, eps: float = 2.0,
+              device_id: int = 0):
+    """Batched ``ft_grandprix.raycast.fakelidar``: origins [n, 2] px, cosines / sines [n, R] -> (scan [n, R], points [n, R, 2])."""
+    dt = np.ascontiguousarray(dt, dtype=np.float64)
+    o = np.ascontiguousarray(origins, dtype=np.float64).reshape(-1, 2)
+    c = np.ascontiguousarray(cosines, dtype=np.float64).reshape(len(o), -1)
+    s = np.ascontiguousarray(sines, dtype=np.float64).reshape(len(o), -1)
+    scan = np.empty_like(c)
+    pts = np.empty(c.shape + (2,), dtype=np.float64)
+    if lib.prefix == "ftgp_":
+        lib.check(lib.fn("fakelidar")(device_id, _ptr(dt), dt.shape[0], dt.shape[1], len(o), _ptr(o), c.shape[1], _ptr(c), _ptr(s),
+                                      float(eps), _ptr(scan), _ptr(pts)))
+    else:   # the oracle exposes the single-origin form
+        for k in range(len(o)):
+            lib.check(lib.fn("fakelidar")(float(o[k, 0]), float(o[k, 1]), _ptr(dt), dt.shape[0], dt.shape[1], c.shape[1],
+                                          c[k].ctypes.data_as(C.c_void_p), s[k].ctypes.data_as(C.c_void_p), float(eps),
+                                          scan[k].ctypes.data_as(C.c_void_p), pts[k].ctypes.data_as(C.c_void_p)))
+    return scan, pts
 
 
 def comm_unique_id(lib: CLib) -> bytes:

@@ -646,6 +646,35 @@ int ftgp_metrics_allgather(FtgpEnv* e, double* out)
     return 0;
 }
 
+int ftgp_fakelidar(int device_id, const double* dt, int H, int W, int n_origins, const double* origins, int rangefinders,
+                   const double* cosines, const double* sines, double eps, double* scan, double* points)
+{
+    if (!dt || !origins || !cosines || !sines || !scan || !points || H < 1 || W < 1 || n_origins < 1 || rangefinders < 1)
+        return fail(FTGP_ERR_ARG, "fakelidar: bad argument%s");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(FTGP_ERR_NO_DEVICE, "no HIP device: this library has no CPU fallback%s");
+    if (device_id < 0 || device_id >= ndev) return fail(FTGP_ERR_ARG, "device_id out of range%s");
+    HIP_TRY(hipSetDevice(device_id));
+    const size_t n = (size_t)n_origins * rangefinders, ndt = (size_t)H * W;
+    double *d_dt = nullptr, *d_o = nullptr, *d_c = nullptr, *d_s = nullptr, *d_scan = nullptr, *d_pts = nullptr; int* d_err = nullptr;
+    int rc = 0, herr = 0;
+    auto cleanup = [&]() { void* b[] = { d_dt, d_o, d_c, d_s, d_scan, d_pts, d_err }; for (void* p : b) if (p) (void)hipFree(p); };
+#define FL_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { snprintf(g_err, sizeof g_err, "%s failed: %s", #expr, hipGetErrorString(e_)); cleanup(); return FTGP_ERR_HIP; } } while (0)
+    FL_TRY(hipMalloc(&d_dt, ndt * 8)); FL_TRY(hipMalloc(&d_o, (size_t)n_origins * 16)); FL_TRY(hipMalloc(&d_c, n * 8)); FL_TRY(hipMalloc(&d_s, n * 8));
+    FL_TRY(hipMalloc(&d_scan, n * 8)); FL_TRY(hipMalloc(&d_pts, n * 16)); FL_TRY(hipMalloc(&d_err, 4));
+    FL_TRY(hipMemcpy(d_dt, dt, ndt * 8, hipMemcpyHostToDevice)); FL_TRY(hipMemcpy(d_o, origins, (size_t)n_origins * 16, hipMemcpyHostToDevice));
+    FL_TRY(hipMemcpy(d_c, cosines, n * 8, hipMemcpyHostToDevice)); FL_TRY(hipMemcpy(d_s, sines, n * 8, hipMemcpyHostToDevice));
+    FL_TRY(hipMemset(d_err, 0, 4));
+    hipLaunchKernelGGL(ftgp_fakelidar_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d_dt, H, W, (int)n, rangefinders, d_o, d_c, d_s, eps, d_scan, d_pts, d_err);
+    FL_TRY(hipGetLastError());
+    FL_TRY(hipMemcpy(scan, d_scan, n * 8, hipMemcpyDeviceToHost)); FL_TRY(hipMemcpy(points, d_pts, n * 16, hipMemcpyDeviceToHost));
+    FL_TRY(hipMemcpy(&herr, d_err, 4, hipMemcpyDeviceToHost));
+#undef FL_TRY
+    cleanup();
+    if (herr) rc = fail(FTGP_ERR_ARG, "fakelidar: IndexError (a ray left the image through the right or bottom edge)%s");
+    return rc;
+}
+
 int ftgp_last_kernel_ms(FtgpEnv* e, float* ms)
 {
     if (!e || !ms) return fail(FTGP_ERR_ARG, "null argument%s");

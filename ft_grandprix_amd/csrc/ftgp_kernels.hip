@@ -871,6 +871,37 @@ __global__ void ftgp_set_pose_kernel(DeviceParams P, const double* __restrict__ 
     s.x = o[0]; s.y = o[1]; s.qw = o[3] / n; s.qz = o[6] / n; s.vx = o[7]; s.vy = o[8]; s.wz = o[12];
 }
 
+// fakelidar-compat (raycast.py:5-21): one ray per lane, binary64, same operation order as the Python loop.
+__global__ void ftgp_fakelidar_kernel(const double* __restrict__ dt, int H, int W, int n_rays_total, int R,
+                                      const double* __restrict__ origins, const double* __restrict__ cosines, const double* __restrict__ sines,
+                                      double eps, double* __restrict__ scan, double* __restrict__ points, int* __restrict__ index_error)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rays_total) return;
+    const int o = i / R;
+    double x = origins[2 * o], y = origins[2 * o + 1];
+    const double dx = cosines[i], dy = sines[i];
+    double distance = 0.0;
+    bool bad = false;
+    long yi = (long)y, xi = (long)x;                          // int(): truncation toward zero
+    if (yi < 0) yi += H;
+    if (xi < 0) xi += W;                                      // numpy negative-index wrap
+    double nearest = 0.0;
+    if (yi < 0 || yi >= H || xi < 0 || xi >= W) bad = true; else nearest = dt[(size_t)yi * W + xi];
+    for (int guard = 0; guard < (1 << 20) && !bad && nearest > eps && 0 <= x && x <= W && 0 <= y && y <= H; ++guard) {
+        distance += nearest;
+        x += dx * nearest;
+        y += dy * nearest;
+        yi = (long)y; xi = (long)x;
+        if (yi < 0) yi += H;
+        if (xi < 0) xi += W;
+        if (yi < 0 || yi >= H || xi < 0 || xi >= W) { bad = true; break; }
+        nearest = dt[(size_t)yi * W + xi];
+    }
+    if (bad) atomicOr(index_error, 1);
+    scan[i] = distance; points[2 * i] = x; points[2 * i + 1] = y;
+}
+
 // Metrics record (FTGP_METRIC_DOUBLES): one block, deterministic tree reduction (integers are exact in f64).
 __global__ void __launch_bounds__(256) ftgp_metrics_kernel(DeviceParams P, double* __restrict__ out)
 {

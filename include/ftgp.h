@@ -209,6 +209,21 @@ int ftgp_comm_unique_id(uint8_t id_out[128]);
 int ftgp_comm_init(FtgpEnv *env, const uint8_t id[128], int rank, int world_size);
 int ftgp_metrics_allgather(FtgpEnv *env, double *out);
 
+/*
+ * fakelidar-compatible 2-D sphere tracing (ft_grandprix/raycast.py:5-21), batched over origins, one ray per lane.
+ *   dt        double[H][W]   distance transform of the track image in pixels (the caller computes it, as the
+ *                            reference does with scipy: custom.py:1149-1153, raycast.py:24-27)
+ *   origins   double[n_origins][2]   (orig_x, orig_y) in pixels
+ *   cosines / sines  double[n_origins][rangefinders]
+ *   scan      double[n_origins][rangefinders]        accumulated distance per ray (pixels)
+ *   points    double[n_origins][rangefinders][2]     end point per ray
+ * Same loop as the reference: while dt[int(y), int(x)] > eps and 0 <= x <= W and 0 <= y <= H: advance by dt.
+ * int() truncates toward zero and negative indices wrap like numpy's; an index past the end is the reference's
+ * IndexError and is reported as FTGP_ERR_ARG.  Standalone: needs no FtgpEnv.
+ */
+int ftgp_fakelidar(int device_id, const double *dt, int H, int W, int n_origins, const double *origins, int rangefinders,
+                   const double *cosines, const double *sines, double eps, double *scan, double *points);
+
 /* Timing of the most recent ftgp_step / ftgp_rollout launch sequence, measured with HIP events on the handle's stream (ms). */
 int ftgp_last_kernel_ms(FtgpEnv *env, float *ms);
 

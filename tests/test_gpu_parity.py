@@ -255,3 +255,21 @@ def test_rccl_communicator_single_rank(product):
         assert rec.shape == (1, capi.METRIC_DOUBLES)
         np.testing.assert_array_equal(rec[0], g.metrics_local())
         assert rec[0][0] == 8 * 40 and rec[0][1] == 8
+
+
+@pytest.mark.parametrize("name", ["track", "small-circle"])
+def test_g2_fakelidar_on_gpu_bit_exact(product, name):
+    """Row a3: the fakelidar-compat kernel against the outputs of the reference's own raycast.fakelidar (fixture G2)."""
+    from scipy.ndimage import distance_transform_edt
+    gld = np.load(golden("g2_fakelidar.npz"))
+    t = load_track(name)
+    dt = distance_transform_edt(~t.wall_mask())
+    origins = gld[f"{name}_origins"]
+    for R in (36, 1080):
+        ang = gld[f"{name}_{R}_angles"]
+        scan, pts = capi.fakelidar(product, dt, origins, np.cos(ang), np.sin(ang), eps=2.0)
+        np.testing.assert_array_equal(scan, gld[f"{name}_{R}_scan"])
+        np.testing.assert_array_equal(pts, gld[f"{name}_{R}_points"])
+    # a ray that leaves through the right edge is the reference's IndexError
+    with pytest.raises(capi.FtgpError):
+        capi.fakelidar(product, np.full((64, 64), 10.0), [[60.0, 32.0]], [[1.0]], [[0.0]])
