@@ -81,13 +81,35 @@ def main():
     track = load_track(args.track)
     seed = 1234
     # rank r owns envs [r * envs_per_gpu, (r + 1) * envs_per_gpu) of one world-sized batch (BASELINE.json configs[3] at N = 8)
+    n_dev = lib.fn("device_count")()
     env = capi.Env(lib, track, n_envs=args.envs_per_gpu, cars_per_env=args.cars, n_rays=args.rays, spawn_mode=1,
-                   seed=seed, device_id=local_rank, env_base=rank * args.envs_per_gpu)
+                   seed=seed, device_id=local_rank % n_dev, env_base=rank * args.envs_per_gpu)
+    collective = "none (1 rank)"
+    gloo_gather = None
     if world > 1:
         import torch
-        uid = [capi.comm_unique_id(lib) if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        env.comm_init(uid[0], rank, world)
+        from ft_grandprix_amd import dist as ftdist
+        collective = "rccl ncclAllGather (xGMI), side stream"
+        ok = 1
+        try:
+            if world > n_dev:
+                raise RuntimeError("more ranks than GPUs: RCCL refuses two ranks on one device")
+            uid = [capi.comm_unique_id(lib) if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            env.comm_init(uid[0], rank, world)
+        except Exception as exc:   # rehearsal on a box with fewer GPUs than ranks: keep going over gloo, and say so
+            ok = 0
+            if world <= n_dev:
+                print(f"[rank {rank}] RCCL communicator failed ({exc}); using the gloo gather", file=sys.stderr)
+        flag = torch.tensor([ok]); dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag[0]) == 0:
+            gloo_gather = ftdist.GlooGather()
+            collective = "gloo all_gather (RCCL communicator unavailable: ranks > GPUs)"
+
+    def gather():
+        if gloo_gather is not None:
+            return gloo_gather.all_gather(env.metrics_local())
+        return env.metrics_allgather()
 
     def barrier():
         if dist is not None:
@@ -95,7 +117,7 @@ def main():
 
     # warmup (untimed)
     env.rollout(args.policy, args.warmup)
-    env.metrics_allgather()
+    gather()
     env.last_kernel_ms()
 
     best_ms = None
@@ -103,7 +125,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.repeats):
         env.rollout(args.policy, args.steps)     # EXACTLY K steps per launch
-        metrics = env.metrics_allgather()        # the only collective; side stream
+        metrics = gather()                       # the only collective; side stream
         kms = env.last_kernel_ms()               # HIP events on the launch stream; also synchronises
         best_ms = kms if best_ms is None else min(best_ms, kms)
     barrier()
@@ -138,7 +160,7 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "frac_of_measured_copy_6290": achieved / HBM_MEASURED_COPY_GBS,
                          "rays_per_s": args.envs_per_gpu * args.cars * args.rays * args.steps / kernel_s},
-            "metrics_allgather": {"ranks": int(metrics.shape[0]), "sum_laps": float(metrics[:, 2].sum()),
+            "metrics_allgather": {"collective": collective, "ranks": int(metrics.shape[0]), "sum_laps": float(metrics[:, 2].sum()),
                                   "sum_steps": float(metrics[:, 0].sum())},
         }
         if world == 1 and not args.no_cpu_baseline:

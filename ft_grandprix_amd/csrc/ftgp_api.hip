@@ -71,8 +71,8 @@ struct FtgpEnv {
     hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_metrics = nullptr;
     bool timed = false;
     // device buffers
-    uint8_t* d_coarse = nullptr; uint2* d_rank = nullptr; uint8_t* d_fine = nullptr;
-    double* d_path = nullptr; double* d_spawn = nullptr; float* d_ray = nullptr; void* d_veh = nullptr;
+    uint8_t* d_coarse = nullptr; uint2* d_rank = nullptr; uint8_t* d_fine = nullptr; uint8_t* d_field = nullptr;
+    double* d_path = nullptr; double* d_spawn = nullptr; float* d_ray = nullptr; void* d_veh = nullptr; DeviceParams* d_params = nullptr;
     CarState* d_cars = nullptr; float* d_ranges = nullptr; int64_t* d_steps = nullptr;
     uint8_t* d_env_mask = nullptr; uint8_t* d_car_mask = nullptr; double* d_ctrl = nullptr; double* d_pose = nullptr;
     double* d_metrics = nullptr; double* d_gather = nullptr;
@@ -114,6 +114,7 @@ void chessboard_dt(const std::vector<uint8_t>& occ, int W, int H, std::vector<in
 //   rank   : per 32 blocks {non-empty bits, number of non-empty blocks before the word} -> index into fine
 //   coarse : one nibble per block = chessboard distance in blocks to the nearest non-empty block, clamped to 15
 struct HostGrid {
+    std::vector<uint8_t> field;       // flat per-pixel distance, clamp 255
     int nbx = 0, nby = 0, nwpr = 0, n_fine = 0;
     std::vector<uint8_t> coarse;
     std::vector<uint2> rank;
@@ -133,6 +134,8 @@ void build_grid(const FtgpTrack& t, HostGrid& g)
     std::vector<int> dpx, dblk;
     chessboard_dt(wall, W, H, dpx);
     chessboard_dt(nonempty, g.nbx, g.nby, dblk);
+    g.field.resize((size_t)W * H);
+    for (size_t i = 0; i < g.field.size(); ++i) g.field[i] = (uint8_t)std::min(255, dpx[i]);
     g.rank.assign((size_t)g.nby * g.nwpr, make_uint2(0u, 0u));
     g.fine.clear(); g.n_fine = 0;
     for (int by = 0; by < g.nby; ++by)
@@ -165,11 +168,12 @@ inline int pad16(size_t n) { return (int)((n + 15) & ~(size_t)15); }
 int lds_layout(DeviceParams& P, int cpb)
 {
     int o = 0;
+    P.off_params = o; o += pad16(sizeof(DeviceParams));
     P.off_veh = o;    o += pad16(sizeof(VehLds));
-    P.off_fine = o;   o += std::max(16, pad16((size_t)P.n_fine * 32));
-    P.off_rank = o;   o += pad16((size_t)P.nby * P.nwpr * 8);
+    P.off_fine = o;   o += P.use_field ? 0 : std::max(16, pad16((size_t)P.n_fine * 32));
+    P.off_rank = o;   o += P.use_field ? 0 : pad16((size_t)P.nby * P.nwpr * 8);
     P.off_path = o;   o += pad16(sizeof(double) * 2 * FTGP_PATH_POINTS);
-    P.off_coarse = o; o += pad16(((size_t)P.nbx * P.nby + 1) / 2);
+    P.off_coarse = o; o += P.use_field ? 0 : pad16(((size_t)P.nbx * P.nby + 1) / 2);
     P.off_ray = o;    o += 2 * P.ray_floats * (int)sizeof(float);
     P.off_state = o;  o += cpb * (int)sizeof(CarCore);
     P.off_scan = o;   o += cpb * P.scan_floats * (int)sizeof(float);
@@ -196,10 +200,12 @@ int launch_steps(FtgpEnv* e, int policy, int n_steps)
     const int blocks = (e->P.n_cars + cpb - 1) / cpb;
     HIP_TRY(hipEventRecord(e->ev_start, e->stream));
     if (n_steps > 0) {
-        if (e->multi)
-            hipLaunchKernelGGL(ftgp_step_kernel<true>, dim3(blocks), dim3(cpb * FTGP_WAVE), (size_t)e->P.lds_bytes, e->stream, e->P, policy, n_steps, cpb);
-        else
-            hipLaunchKernelGGL(ftgp_step_kernel<false>, dim3(blocks), dim3(cpb * FTGP_WAVE), (size_t)e->P.lds_bytes, e->stream, e->P, policy, n_steps, cpb);
+        const dim3 grid(blocks), block(cpb * FTGP_WAVE);
+        const size_t lds = (size_t)e->P.lds_bytes;
+        if (e->multi && e->P.use_field) hipLaunchKernelGGL((ftgp_step_kernel<true, true>), grid, block, lds, e->stream, e->d_params, policy, n_steps, cpb);
+        else if (e->multi)              hipLaunchKernelGGL((ftgp_step_kernel<true, false>), grid, block, lds, e->stream, e->d_params, policy, n_steps, cpb);
+        else if (e->P.use_field)        hipLaunchKernelGGL((ftgp_step_kernel<false, true>), grid, block, lds, e->stream, e->d_params, policy, n_steps, cpb);
+        else                            hipLaunchKernelGGL((ftgp_step_kernel<false, false>), grid, block, lds, e->stream, e->d_params, policy, n_steps, cpb);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(e->ev_stop, e->stream));
@@ -257,7 +263,7 @@ int ftgp_destroy(FtgpEnv* e)
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->side) (void)hipStreamSynchronize(e->side);
     if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
-    void* bufs[] = { e->d_veh, e->d_coarse, e->d_rank, e->d_fine, e->d_path, e->d_spawn, e->d_ray, e->d_cars, e->d_ranges,
+    void* bufs[] = { e->d_field, e->d_params, e->d_veh, e->d_coarse, e->d_rank, e->d_fine, e->d_path, e->d_spawn, e->d_ray, e->d_cars, e->d_ranges,
                      e->d_steps, e->d_env_mask, e->d_car_mask, e->d_ctrl, e->d_pose, e->d_metrics, e->d_gather };
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (e->ev_start) (void)hipEventDestroy(e->ev_start);
@@ -334,6 +340,8 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
     P.scan_floats = (1 + (cfg->n_rays - 2 * P.eighth) + 3) & ~3;
     P.ray_floats = (cfg->n_rays + 3) & ~3;
     P.snap_eps = 1.0f / 512.0f;
+    P.use_field = 1;                                                // default: flat per-pixel field from L2 (fewest instructions per march iteration)
+    if (const char* sv = getenv("FTGP_FIELD")) { if (!strcmp(sv, "lds")) P.use_field = 0; else if (!strcmp(sv, "global")) P.use_field = 1; }
     if (t.width > 8192 || t.height > 8192) { snprintf(g_err, sizeof g_err, "images above 8192 pixels are not supported"); ftgp_destroy(e); return FTGP_ERR_ARG; }
     const int scan_floats = P.ray_floats;
     std::vector<float> ray(2 * (size_t)scan_floats, 0.0f);
@@ -356,7 +364,11 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
         const int unit = e->multi ? cfg->cars_per_env : 1;
         int want = 16;
         if (const char* sv = getenv("FTGP_CARS_PER_BLOCK")) { const int c = atoi(sv); if (c >= 1 && c <= 16) want = c; }
-        int cpb = (want / unit) * unit;
+        // small batches: fewer cars per workgroup so that every CU gets work (256 CUs)
+        const int n_units = P.n_cars / unit;
+        const int spread = std::max(1, n_units / 256) * unit;
+        int cpb = std::min((want / unit) * unit, std::max(unit, spread));
+        if (getenv("FTGP_CARS_PER_BLOCK")) cpb = (want / unit) * unit;
         while (cpb >= unit && lds_layout(P, cpb) > 160 * 1024) cpb -= unit;
         if (cpb < unit) {
             snprintf(g_err, sizeof g_err, "track grid (%d non-empty 8x8 blocks of %dx%d) + %d-ray scan do not fit the 160 KiB LDS",
@@ -367,12 +379,17 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
         e->cars_per_block = cpb;
         lds_layout(P, cpb);
     }
-    CREATE_TRY(hipFuncSetAttribute((const void*)ftgp_step_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    CREATE_TRY(hipFuncSetAttribute((const void*)ftgp_step_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CREATE_TRY(hipFuncSetAttribute((const void*)ftgp_step_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CREATE_TRY(hipFuncSetAttribute((const void*)ftgp_step_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CREATE_TRY(hipFuncSetAttribute((const void*)ftgp_step_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CREATE_TRY(hipFuncSetAttribute((const void*)ftgp_step_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 
-    const size_t sz_fine = (size_t)(P.off_rank - P.off_fine), sz_rank = (size_t)(P.off_path - P.off_rank);
-    const size_t sz_path = (size_t)(P.off_coarse - P.off_path), sz_coarse = (size_t)(P.off_ray - P.off_coarse);
+    const size_t sz_fine = (size_t)std::max(16, pad16((size_t)P.n_fine * 32)), sz_rank = (size_t)pad16((size_t)P.nby * P.nwpr * 8);
+    const size_t sz_path = (size_t)pad16(sizeof(double) * 2 * FTGP_PATH_POINTS), sz_coarse = (size_t)pad16(((size_t)P.nbx * P.nby + 1) / 2);
     const size_t sz_ray = (size_t)(P.off_state - P.off_ray);
+    CREATE_TRY(hipMalloc(&e->d_field, grid.field.size()));
+    CREATE_TRY(hipMemcpy(e->d_field, grid.field.data(), grid.field.size(), hipMemcpyHostToDevice));
+    P.field = e->d_field;
     {
         std::vector<unsigned char> vimg((size_t)pad16(sizeof(VehLds)), 0);
         VehLds vl; vl.v = P.veh; for (int i = 0; i < 4; ++i) vl.wheel_load[i] = P.wheel_load[i];
@@ -408,6 +425,12 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
     CREATE_TRY(hipMemset(e->d_steps, 0, sizeof(int64_t) * (size_t)P.n_envs));
     P.coarse = e->d_coarse; P.rank = e->d_rank; P.fine = e->d_fine; P.path = e->d_path; P.spawn = e->d_spawn;
     P.ray_bx = e->d_ray; P.ray_by = e->d_ray + scan_floats; P.cars = e->d_cars; P.ranges = e->d_ranges; P.steps = e->d_steps;
+    {   // device image of the parameter block (padded to 16 B for the LDS staging copy)
+        std::vector<unsigned char> pimg((size_t)pad16(sizeof(DeviceParams)), 0);
+        memcpy(pimg.data(), &P, sizeof(DeviceParams));
+        CREATE_TRY(hipMalloc(&e->d_params, pimg.size()));
+        CREATE_TRY(hipMemcpy(e->d_params, pimg.data(), pimg.size(), hipMemcpyHostToDevice));
+    }
 #undef CREATE_TRY
     int rc = ftgp_reset(e, nullptr);
     if (rc != 0) { ftgp_destroy(e); return rc; }
@@ -687,7 +710,9 @@ int ftgp_last_kernel_ms(FtgpEnv* e, float* ms)
 
 const char* ftgp_kernel_name(FtgpEnv* e)
 {
-    return (e && e->multi) ? "ftgp_step_kernel<true>" : "ftgp_step_kernel<false>";
+    if (!e) return "ftgp_step_kernel";
+    if (e->multi) return e->P.use_field ? "ftgp_step_kernel<true, true>" : "ftgp_step_kernel<true, false>";
+    return e->P.use_field ? "ftgp_step_kernel<false, true>" : "ftgp_step_kernel<false, false>";
 }
 
 }  // extern "C"

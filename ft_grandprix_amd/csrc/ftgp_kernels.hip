@@ -45,11 +45,23 @@ __host__ __device__ __forceinline__ int fine_at(const DeviceParams& P, const Lds
     return (L.fine[(idx << 5) + (n >> 1)] >> ((n & 1) << 2)) & 15;
 }
 // wall bit of pixel (cx, cy), which must lie inside the image
+template <bool GF>
+__device__ __forceinline__ bool wall_px(const DeviceParams& P, const LdsView& L, int cx, int cy);
 __host__ __device__ __forceinline__ bool grid_wall(const DeviceParams& P, const LdsView& L, int cx, int cy)
 {
     const int bx = cx >> 3, by = cy >> 3;
     if (coarse_at(P, L, bx, by) != 0) return false;
     return fine_at(P, L, bx, by, cx, cy) == 0;
+}
+
+template <> __device__ __forceinline__ bool wall_px<false>(const DeviceParams& P, const LdsView& L, int cx, int cy) { return grid_wall(P, L, cx, cy); }
+template <> __device__ __forceinline__ bool wall_px<true>(const DeviceParams& P, const LdsView& L, int cx, int cy) { return P.field[cy * P.width + cx] == 0; }
+// no wall pixel within `reach` pixels (chessboard) of pixel (ix, iy)?
+template <bool GF>
+__device__ __forceinline__ bool far_from_walls(const DeviceParams& P, const LdsView& L, int ix, int iy, int reach)
+{
+    if (GF) return (int)P.field[iy * P.width + ix] > reach;
+    return coarse_at(P, L, ix >> 3, iy >> 3) >= ((reach + 7) >> 3) + 1;
 }
 
 // =============================================================================================
@@ -117,10 +129,10 @@ __host__ __device__ __forceinline__ Probe ray_probe(const DeviceParams& P, const
 }
 
 // returns true when the landing point was too close to a pixel boundary to trust floor(): the caller then runs ray_fix()
-__host__ __device__ __forceinline__ bool ray_step(const DeviceParams& P, Ray& r, const Probe& pb, unsigned byte2,
+__host__ __device__ __forceinline__ bool ray_step(const DeviceParams& P, Ray& r, const Probe& pb, unsigned byte2, int kmask,
                                                   int& t_out, int& cur_out, int& hi_out, bool& stepx_out, int& xhi_out, int& yhi_out)
 {
-    const int k = (int)(byte2 >> pb.shift2) & 15;                  // pixel distance (non-empty block) or block distance (empty block)
+    const int k = (int)(byte2 >> pb.shift2) & kmask;               // pixel distance (non-empty block / flat field) or block distance (empty block)
     const bool hit = r.active & pb.nonempty & (k == 0);
     r.result = hit ? fabsf(r.s) : r.result;
     r.active = r.active & !hit;
@@ -174,7 +186,7 @@ __host__ __device__ __forceinline__ float march_grid(const DeviceParams& P, cons
         const uint2 rk = rank[ray_rank_addr(P, r)];
         const Probe pb = ray_probe(P, r, rk);
         int t, cur, hi, xhi, yhi; bool stepx;
-        const bool near = ray_step(P, r, pb, lds[pb.addr2], t, cur, hi, stepx, xhi, yhi);
+        const bool near = ray_step(P, r, pb, lds[pb.addr2], 15, t, cur, hi, stepx, xhi, yhi);
         if (near) t = ray_fix(r, t, cur, hi, stepx);
         ray_commit(P, r, t, cur, stepx, xhi, yhi);
     }
@@ -230,7 +242,7 @@ __device__ __forceinline__ float ray_vs_car(const FtgpVehicle& v, const CarCore*
 #ifndef FTGP_RPL
 #define FTGP_RPL 1
 #endif
-template <bool MULTI>
+template <bool MULTI, bool GF>
 __device__ __forceinline__ void lidar_sweep(const DeviceParams& P, const LdsView& L, const CarCore* st, float* __restrict__ out_global,
                                             float* __restrict__ out_lds, const CarCore* env_cars, int my_slot)
 {
@@ -248,6 +260,8 @@ __device__ __forceinline__ void lidar_sweep(const DeviceParams& P, const LdsView
     const int lane = lane_id();
     const unsigned char* lds_base = reinterpret_cast<const unsigned char*>(L.veh) - P.off_veh;
     const uint2* rank = L.rank;
+    const uint8_t* __restrict__ field = P.field;
+    const int W = P.width;
     for (int base = 0; base < R; base += FTGP_WAVE * FTGP_RPL) {
         Ray ray[FTGP_RPL];
         float dxw[FTGP_RPL], dyw[FTGP_RPL];
@@ -272,14 +286,24 @@ __device__ __forceinline__ void lidar_sweep(const DeviceParams& P, const LdsView
             if (!__any(any_active)) break;
             int t[FTGP_RPL], cur[FTGP_RPL], hi[FTGP_RPL], xhi[FTGP_RPL], yhi[FTGP_RPL]; bool stepx[FTGP_RPL], near[FTGP_RPL];
             uint2 rk[FTGP_RPL]; Probe pb[FTGP_RPL]; unsigned b2[FTGP_RPL];
-            #pragma unroll
-            for (int q = 0; q < FTGP_RPL; ++q) rk[q] = rank[ray_rank_addr(P, ray[q])];          // stage 1: all rays' rank words in flight
-            #pragma unroll
-            for (int q = 0; q < FTGP_RPL; ++q) { pb[q] = ray_probe(P, ray[q], rk[q]); b2[q] = lds_base[pb[q].addr2]; }   // stage 2
+            if (GF) {
+                // flat per-pixel field from L2: one byte, no indirection (pixel-distance semantics for every cell)
+                #pragma unroll
+                for (int q = 0; q < FTGP_RPL; ++q) {
+                    const int tx = ray[q].ix ^ ray[q].mx, ty = ray[q].iy ^ ray[q].my;
+                    pb[q].nonempty = true; pb[q].shift2 = 0; pb[q].addr2 = 0;
+                    b2[q] = field[ty * W + tx];
+                }
+            } else {
+                #pragma unroll
+                for (int q = 0; q < FTGP_RPL; ++q) rk[q] = rank[ray_rank_addr(P, ray[q])];          // stage 1: all rays' rank words in flight
+                #pragma unroll
+                for (int q = 0; q < FTGP_RPL; ++q) { pb[q] = ray_probe(P, ray[q], rk[q]); b2[q] = lds_base[pb[q].addr2]; }   // stage 2
+            }
             bool any_near = false;
             #pragma unroll
             for (int q = 0; q < FTGP_RPL; ++q) {
-                near[q] = ray_step(P, ray[q], pb[q], b2[q], t[q], cur[q], hi[q], stepx[q], xhi[q], yhi[q]);
+                near[q] = ray_step(P, ray[q], pb[q], b2[q], GF ? 255 : 15, t[q], cur[q], hi[q], stepx[q], xhi[q], yhi[q]);
                 any_near |= near[q];
             }
             if (__any(any_near)) {
@@ -296,7 +320,7 @@ __device__ __forceinline__ void lidar_sweep(const DeviceParams& P, const LdsView
                 float r = ray[q].result;
                 if (MULTI) {
                     for (int k = 0; k < P.cars_per_env; ++k) {
-                        if (k == my_slot) continue;
+                        if (k == my_slot || env_cars[k].finished) continue;      // shadowed cars are invisible (custom.py:1441-1466)
                         const float rc = ray_vs_car(v, env_cars + k, lcx, lcy, dxw[q], dyw[q]);
                         if (rc < INFINITY && (r < 0.0f || rc < r)) r = rc;
                     }
@@ -392,6 +416,7 @@ struct Dyn { double x, y, qw, qz, vx, vy, wz, qs, qsd, w[4]; };
 
 // Chassis circles against wall pixels: the (2nx+1) x (2ny+1) candidate cells of each circle are tested
 // one per lane; the deepest penetration (ties: first in raster order) is picked by a wave reduction.
+template <bool GF>
 __device__ __forceinline__ void wall_contact(const DeviceParams& P, const LdsView& L, const Dyn& s, double ch, double sh, Force& f)
 {
     const FtgpVehicle& v = L.veh->v;
@@ -400,22 +425,22 @@ __device__ __forceinline__ void wall_contact(const DeviceParams& P, const LdsVie
     const double r = v.contact_radius;
     const int nx = (int)ceil(r * P.inv_px_x), ny = (int)ceil(r * P.inv_px_y);
     const int reach = (nx > ny ? nx : ny) + 1;
-    const int need = ((reach + 7) >> 3) + 1;     // block distance at which no wall pixel can be within reach
     const int wx = 2 * nx + 1, ncell = wx * (2 * ny + 1);
     const int lane = lane_id();
+    #pragma unroll 1
     for (int k = 0; k < 3; ++k) {
         const double rxw = ch * v.contact_x[k], ryw = sh * v.contact_x[k];
         const double px = s.x + rxw, py = s.y + ryw;
         const double u = (px - P.origin_x) * P.inv_px_x, w = (P.origin_y - py) * P.inv_px_y;
         const int ix = (int)floor(u), iy = (int)floor(w);
         if (ix < 0 || ix >= W || iy < 0 || iy >= H) continue;
-        if (coarse_at(P, L, ix >> 3, iy >> 3) >= need) continue;
+        if (far_from_walls<GF>(P, L, ix, iy, reach)) continue;
         double mypen = 0.0; int myc = 0x7fffffff;
         for (int base = 0; base < ncell; base += FTGP_WAVE) {
             const int c = base + lane;
             if (c < ncell) {
                 const int cy = iy + (c / wx - ny), cx = ix + (c % wx - nx);
-                if (cx >= 0 && cx < W && cy >= 0 && cy < H && grid_wall(P, L, cx, cy)) {
+                if (cx >= 0 && cx < W && cy >= 0 && cy < H && wall_px<GF>(P, L, cx, cy)) {
                     const double x0 = P.origin_x + (double)cx * sx, x1 = x0 + sx;
                     const double y1 = P.origin_y - (double)cy * sy, y0 = y1 - sy;
                     const double qx = px < x0 ? x0 : (px > x1 ? x1 : px);
@@ -466,8 +491,9 @@ __device__ __forceinline__ void car_contact(const DeviceParams& P, const LdsView
 {
     const FtgpVehicle& v = L.veh->v;
     const double r2 = 2.0 * v.contact_radius;
+    if (env_cars[my_slot].finished) return;          // a shadowed car collides with nothing (custom.py:1452-1457)
     for (int k = 0; k < P.cars_per_env; ++k) {
-        if (k == my_slot) continue;
+        if (k == my_slot || env_cars[k].finished) continue;
         const CarCore* b = env_cars + k;
         const double bx = b->x, by = b->y, bqw = b->qw, bqz = b->qz, bvx = b->vx, bvy = b->vy, bwz = b->wz;
         const double cb = 1.0 - 2.0 * (bqz * bqz), sb = 2.0 * (bqw * bqz);
@@ -495,7 +521,7 @@ __device__ __forceinline__ void car_contact(const DeviceParams& P, const LdsView
 }
 
 // new dynamic state from the pre-step state in LDS (other cars of the env are read pre-step too)
-template <bool MULTI>
+template <bool MULTI, bool GF>
 __device__ __forceinline__ Dyn integrate(const DeviceParams& P, const LdsView& L, const CarCore* st, const CarCore* env_cars, int my_slot)
 {
     const FtgpVehicle& v = L.veh->v;
@@ -509,8 +535,6 @@ __device__ __forceinline__ Dyn integrate(const DeviceParams& P, const LdsView& L
     const double q = s.qs;
     const double dfl = q * (1.0 + q * (0.375 + q * (0.140625 + q * -0.0722656)));
     const double dfr = q * (1.0 + q * (-0.375 + q * (0.140625 + q * 0.0722656)));
-    const double cw[4] = { spec_cos(dfl), spec_cos(dfr), 1.0, 1.0 };
-    const double sw[4] = { spec_sin(dfl), spec_sin(dfr), 0.0, 0.0 };
     // velocity servo on the tendon = mean wheel spin, mushr.em.xml:180,191-196
     const double wbar = 0.25 * (((s.w[0] + s.w[1]) + s.w[2]) + s.w[3]);
     double fa = v.throttle_kv * (u_speed - v.throttle_gear * wbar);
@@ -519,13 +543,18 @@ __device__ __forceinline__ Dyn integrate(const DeviceParams& P, const LdsView& L
     const double ta = (v.throttle_gear * 0.25) * fa;
     Force f = { 0.0, 0.0, 0.0 };
     Dyn o;
-    #pragma unroll
+    // rolled on purpose (register pressure): the rear wheels evaluate the polynomials at 0, which gives exactly (1, 0)
+    #pragma unroll 1
     for (int i = 0; i < 4; ++i) {
-        const double rxw = ch * v.wheel_x[i] - sh * v.wheel_y[i];
-        const double ryw = sh * v.wheel_x[i] + ch * v.wheel_y[i];
+        const double ang = (i == 0) ? dfl : ((i == 1) ? dfr : 0.0);
+        const double cwi = spec_cos(ang), swi = spec_sin(ang);
+        const double wi = (i == 0) ? s.w[0] : ((i == 1) ? s.w[1] : ((i == 2) ? s.w[2] : s.w[3]));
+        const double wx_ = v.wheel_x[i], wy_ = v.wheel_y[i];
+        const double rxw = ch * wx_ - sh * wy_;
+        const double ryw = sh * wx_ + ch * wy_;
         const double vpx = s.vx - s.wz * ryw, vpy = s.vy + s.wz * rxw;
-        const double fdx = ch * cw[i] - sh * sw[i], fdy = sh * cw[i] + ch * sw[i];
-        const double vlong = (vpx * fdx + vpy * fdy) - v.wheel_radius * s.w[i];
+        const double fdx = ch * cwi - sh * swi, fdy = sh * cwi + ch * swi;
+        const double vlong = (vpx * fdx + vpy * fdy) - v.wheel_radius * wi;
         const double vlat = vpy * fdx - vpx * fdy;
         double flong = -(v.tire_damping * vlong), flat = -(v.tire_damping * vlat);
         const double lim = v.friction * L.veh->wheel_load[i];
@@ -533,9 +562,10 @@ __device__ __forceinline__ Dyn integrate(const DeviceParams& P, const LdsView& L
         if (m2 > lim * lim) { const double sc = lim / sqrt(m2); flong = flong * sc; flat = flat * sc; }
         const double fx = flong * fdx - flat * fdy, fy = flong * fdy + flat * fdx;
         f.fx += fx; f.fy += fy; f.tz += rxw * fy - ryw * fx;
-        o.w[i] = (v.wheel_inertia * s.w[i] + dt * (ta - v.wheel_radius * flong)) / (v.wheel_inertia + dt * v.wheel_damping);
+        const double wn = (v.wheel_inertia * wi + dt * (ta - v.wheel_radius * flong)) / (v.wheel_inertia + dt * v.wheel_damping);
+        if (i == 0) o.w[0] = wn; else if (i == 1) o.w[1] = wn; else if (i == 2) o.w[2] = wn; else o.w[3] = wn;
     }
-    wall_contact(P, L, s, ch, sh, f);
+    if (!st->finished) wall_contact<GF>(P, L, s, ch, sh, f);
     if (MULTI) car_contact(P, L, s, ch, sh, env_cars, my_slot, f);
     o.vx = s.vx + dt * (f.fx / v.mass);
     o.vy = s.vy + dt * (f.fy / v.mass);
@@ -679,11 +709,14 @@ __device__ __forceinline__ void stage16(void* dst, const void* src, int bytes)
 
 __device__ __forceinline__ LdsView stage_track(const DeviceParams& P, unsigned char* lds)
 {
+    stage16(lds + P.off_params, &P, P.off_veh - P.off_params);   // the parameter block itself: later reads come from LDS, not from ~70 pinned SGPRs
     stage16(lds + P.off_veh, P.veh_dev, P.off_fine - P.off_veh);
-    stage16(lds + P.off_fine, P.fine, P.off_rank - P.off_fine);
-    stage16(lds + P.off_rank, P.rank, P.off_path - P.off_rank);
+    if (!P.use_field) {
+        stage16(lds + P.off_fine, P.fine, P.off_rank - P.off_fine);
+        stage16(lds + P.off_rank, P.rank, P.off_path - P.off_rank);
+        stage16(lds + P.off_coarse, P.coarse, P.off_ray - P.off_coarse);
+    }
     stage16(lds + P.off_path, P.path, P.off_coarse - P.off_path);
-    stage16(lds + P.off_coarse, P.coarse, P.off_ray - P.off_coarse);
     stage16(lds + P.off_ray, P.ray_bx, P.off_state - P.off_ray);    // ray_bx and ray_by are one allocation
     LdsView L;
     L.veh = reinterpret_cast<const VehLds*>(lds + P.off_veh);
@@ -701,20 +734,21 @@ __device__ __forceinline__ LdsView stage_track(const DeviceParams& P, unsigned c
 //   driver(previous scan) -> ctrl -> [mj_step: sensors at the current pose, integrate] -> steps += 1 ->
 //   progress at the new pose (= the head of the next loop iteration).
 // =============================================================================================
-template <bool MULTI>
-__global__ void __launch_bounds__(1024) ftgp_step_kernel(DeviceParams P, int policy, int n_steps, int cars_per_block)
+template <bool MULTI, bool GF>
+__global__ void __launch_bounds__(1024) ftgp_step_kernel(const DeviceParams* __restrict__ Pg, int policy, int n_steps, int cars_per_block)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const DeviceParams& P = *reinterpret_cast<const DeviceParams*>(lds + Pg->off_params);   // valid after stage_track + barrier
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ci = __builtin_amdgcn_readfirstlane((int)blockIdx.x * cars_per_block + wave);
+    const LdsView L = stage_track(*Pg, lds);
+    __syncthreads();
     const bool live = ci < P.n_cars;
     const int env = live ? ci / P.cars_per_env : 0;
     const int my_slot = MULTI ? wave % P.cars_per_env : 0;
     const bool need_scan = (policy == FTGP_POLICY_NIDC || policy == FTGP_POLICY_FAST);
     const int scan_floats = P.scan_floats;
-
-    const LdsView L = stage_track(P, lds);
     CarCore* states = reinterpret_cast<CarCore*>(lds + P.off_state);
     CarCore* st = states + wave;
     const CarCore* env_cars = states + (wave - my_slot);
@@ -740,16 +774,24 @@ __global__ void __launch_bounds__(1024) ftgp_step_kernel(DeviceParams P, int pol
                 policy_apply(P, policy, scan, st, ci, steps);
                 wave_lds_sync();
             }
-            lidar_sweep<MULTI>(P, L, st, my_ranges, scan, env_cars, my_slot);   // sensors at the pre-integration pose
+#ifndef FTGP_ABLATE_K2
+            lidar_sweep<MULTI, GF>(P, L, st, my_ranges, scan, env_cars, my_slot);   // sensors at the pre-integration pose
+#endif
         }
         Dyn nxt;
-        if (live) nxt = integrate<MULTI>(P, L, st, env_cars, my_slot);
+#ifndef FTGP_ABLATE_K1
+        if (live) nxt = integrate<MULTI, GF>(P, L, st, env_cars, my_slot);
+#else
+        if (live) { nxt.x = st->x; nxt.y = st->y; nxt.qw = st->qw; nxt.qz = st->qz; nxt.vx = st->vx; nxt.vy = st->vy; nxt.wz = st->wz; nxt.qs = st->qs; nxt.qsd = st->qsd; nxt.w[0] = st->w[0]; nxt.w[1] = st->w[1]; nxt.w[2] = st->w[2]; nxt.w[3] = st->w[3]; }
+#endif
         if (MULTI) __syncthreads();          // every car of the env has read the pre-step states
         if (live) {
             if (lane == 0) dyn_store(nxt, st);
             wave_lds_sync();
             steps += 1;
+#ifndef FTGP_ABLATE_K3
             progress_wave(P, L.path, st, steps, P.cars[ci].times);
+#endif
             wave_lds_sync();
         }
         if (MULTI) __syncthreads();          // new states visible before the next step reads them
@@ -787,8 +829,10 @@ __global__ void __launch_bounds__(256) ftgp_policy_kernel(DeviceParams P, int po
     }
 }
 
-template __global__ void ftgp_step_kernel<false>(DeviceParams, int, int, int);
-template __global__ void ftgp_step_kernel<true>(DeviceParams, int, int, int);
+template __global__ void ftgp_step_kernel<false, false>(const DeviceParams*, int, int, int);
+template __global__ void ftgp_step_kernel<true, false>(const DeviceParams*, int, int, int);
+template __global__ void ftgp_step_kernel<false, true>(const DeviceParams*, int, int, int);
+template __global__ void ftgp_step_kernel<true, true>(const DeviceParams*, int, int, int);
 
 // =============================================================================================
 // K4: reset / spawn (custom.py:1089-1128, 1232-1245, 81-87), one car per lane; then K3 at the spawn pose.

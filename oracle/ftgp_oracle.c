@@ -205,6 +205,7 @@ static float ray_vs_cars(const OracleEnv *e, int car_index, double lcx, double l
         int other = env * cpe + k;
         if (other == car_index) continue;
         const Car *b = &e->cars[other];
+        if (b->finished) continue;                    /* shadowed cars are invisible (custom.py:1441-1466) */
         double cb = 1.0 - 2.0 * (b->qz * b->qz), sb = 2.0 * (b->qw * b->qz);
         float relx = (float)(lcx - b->x), rely = (float)(lcy - b->y);
         float ox = fmaf(dxw, -r0, relx), oy = fmaf(dyw, -r0, rely);
@@ -498,10 +499,12 @@ static void car_contact(const OracleEnv *e, int ci, double ch, double sh, Force 
     const int cpe = c->cars_per_env, env = ci / cpe;
     const Car *a = &e->cars[ci];
     const double r2 = 2.0 * v->contact_radius;
+    if (a->finished) return;                          /* a shadowed car collides with nothing (custom.py:1452-1457) */
     for (int k = 0; k < cpe; ++k) {
         int other = env * cpe + k;
         if (other == ci) continue;
         const Car *b = &e->cars[other];
+        if (b->finished) continue;
         double cb = 1.0 - 2.0 * (b->qz * b->qz), sb = 2.0 * (b->qw * b->qz);
         for (int i = 0; i < 3; ++i) {
             double rxw = ch * v->contact_x[i], ryw = sh * v->contact_x[i];
@@ -563,7 +566,7 @@ static void integrate_car(const OracleEnv *e, int ci, Car *out)
         f.fx += fx; f.fy += fy; f.tz += rxw * fy - ryw * fx;
         out->w[i] = (v->wheel_inertia * a->w[i] + dt * (ta - v->wheel_radius * flong)) / (v->wheel_inertia + dt * v->wheel_damping);
     }
-    wall_contact(e, a, ch, sh, &f);
+    if (!a->finished) wall_contact(e, a, ch, sh, &f);
     if (c->cars_per_env > 1) car_contact(e, ci, ch, sh, &f);
     out->vx = a->vx + dt * (f.fx / v->mass);
     out->vy = a->vy + dt * (f.fy / v->mass);

@@ -273,3 +273,60 @@ def test_g2_fakelidar_on_gpu_bit_exact(product, name):
     # a ray that leaves through the right edge is the reference's IndexError
     with pytest.raises(capi.FtgpError):
         capi.fakelidar(product, np.full((64, 64), 10.0), [[60.0, 32.0]], [[1.0]], [[0.0]])
+
+
+def test_adversarial_rays_through_pixel_corners(product, oracle):
+    """LiDAR centres on exact pixel corners / centres and headings at multiples of 45 degrees, in the pixel-aligned
+    frame: many rays run along pixel boundaries or through corners (ties of the DDA).  GPU vs the plain-DDA spec."""
+    import dataclasses
+    t0 = load_track("track")
+    t = dataclasses.replace(t0, px_size_x=0.025, px_size_y=0.025, origin_x=0.0, origin_y=0.0)   # the 'pixel' frame
+    n = 64
+    g, o = both(product, oracle, t, n_envs=n, n_rays=1080, spawn_mode=1, seed=2)
+    with g, o:
+        oracle.dll.oracle_set_lidar_mode(o.h, 2)            # the specification itself (plain DDA)
+        pose = o.pose()
+        rng = np.random.default_rng(0)
+        yaw = (np.pi / 4) * rng.integers(0, 8, n)
+        px = np.floor(pose[:, 0] / 0.025) + rng.choice([0.0, 0.5], n)
+        py = np.floor(-pose[:, 1] / 0.025) + rng.choice([0.0, 0.5], n)
+        # place the LiDAR centre (body x = -0.0525) on the chosen pixel coordinate
+        pose[:, 0] = px * 0.025 + 0.0525 * np.cos(yaw)
+        pose[:, 1] = -py * 0.025 + 0.0525 * np.sin(yaw)
+        pose[:, 3], pose[:, 6] = np.cos(yaw / 2), np.sin(yaw / 2)
+        pose[:, 7:] = 0
+        g.set_pose(pose); o.set_pose(pose)
+        g.step(1); o.step(1)
+        np.testing.assert_array_equal(g.lidar(), o.lidar())
+
+
+def test_finished_cars_become_ghosts(product, oracle):
+    """custom.py:1367-1371,1441-1466: a car that reached lap_target gets the null driver, stops colliding and is invisible."""
+    t = load_track("circle")
+    g, o = both(product, oracle, t, n_envs=6, cars_per_env=3, n_rays=90, lap_target=0)   # lap_target 0: finished at once
+    with g, o:
+        assert g.progress()[:, 4].all()
+        g.rollout("fast", 50); o.rollout("fast", 50)
+        assert_same_state(g, o)
+        np.testing.assert_array_equal(g.ctrl(), 0.0)
+        # nobody sees anybody: identical to single-car worlds spawned at the same offsets
+        r = g.lidar().reshape(6, 3, 90)
+        np.testing.assert_array_equal(r[0], r[1])
+
+
+def test_both_acceleration_structures_return_the_same_bits(product, oracle, monkeypatch):
+    """The LiDAR specification is independent of the skipping structure: flat per-pixel field (L2) == two-level LDS grid == oracle."""
+    t = load_track("inkscape")
+    kw = dict(n_envs=64, n_rays=1080, spawn_mode=1, seed=21)
+    monkeypatch.setenv("FTGP_FIELD", "global"); a = capi.Env(product, t, **kw)
+    monkeypatch.setenv("FTGP_FIELD", "lds");    b = capi.Env(product, t, **kw)
+    monkeypatch.delenv("FTGP_FIELD")
+    o = capi.Env(oracle, t, **kw); oracle.dll.oracle_set_threads(o.h, 8)
+    with a, b, o:
+        assert a.kernel_name() != b.kernel_name()
+        for e in (a, b, o):
+            e.rollout("fast", 300)
+        np.testing.assert_array_equal(a.lidar(), b.lidar())
+        np.testing.assert_array_equal(a.pose(), b.pose())
+        np.testing.assert_array_equal(a.progress(), b.progress())
+        assert_same_state(a, o); assert_same_state(b, o)
