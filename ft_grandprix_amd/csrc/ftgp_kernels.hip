@@ -522,7 +522,7 @@ __device__ __forceinline__ void car_contact(const DeviceParams& P, const LdsView
 
 // new dynamic state from the pre-step state in LDS (other cars of the env are read pre-step too)
 template <bool MULTI, bool GF>
-__device__ __forceinline__ Dyn integrate(const DeviceParams& P, const LdsView& L, const CarCore* st, const CarCore* env_cars, int my_slot)
+__device__ __attribute__((noinline)) Dyn integrate(const DeviceParams& P, const LdsView& L, const CarCore* st, const CarCore* env_cars, int my_slot)
 {
     const FtgpVehicle& v = L.veh->v;
     const double dt = P.dt;
@@ -597,7 +597,7 @@ __device__ __forceinline__ void dyn_store(const Dyn& o, CarCore* st)
 // =============================================================================================
 struct Ctrl { double speed, steer, last_steer; };
 
-__device__ __forceinline__ void policy_disparity(const DeviceParams& P, float* __restrict__ scan, Ctrl& ctl, bool fast)
+__device__ __attribute__((noinline)) void policy_disparity(const DeviceParams& P, float* __restrict__ scan, Ctrl& ctl, bool fast)
 {
     const int lane = lane_id();
     const int n = P.n_rays;
