@@ -29,6 +29,19 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_MEASURED_COPY_GBS = 6290.0
 
 
+def measured_traffic(n_envs, n_rays, cars, policy, steps):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (tools/traffic.sh: FETCH_SIZE and WRITE_SIZE in
+    separate runs, KB -> bytes; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  The counters cannot
+    be read from inside this process, so the per-env-step figure of the same configuration is scaled to this launch."""
+    p = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if not os.path.exists(p):
+        return None
+    t = json.load(open(p))
+    if (t.get("n_envs"), t.get("n_rays", 1080), t.get("cars", 1), t.get("policy", "fast")) != (n_envs, n_rays, cars, policy):
+        return None
+    return t["traffic_bytes_per_env_step"] * n_envs * steps
+
+
 def cpu_baseline(track, n_rays, policy, cars, seed):
     """The CPU oracle ("port") on a bounded sample of the same workload, on this host's cores (rank 0, N = 1 only)."""
     from tests.helpers import load_oracle
@@ -155,7 +168,8 @@ def main():
                        "envs_per_gpu": args.envs_per_gpu, "n_rays": args.rays, "cars_per_env": args.cars,
                        "policy": args.policy, "steps_per_launch": args.steps, "parallelism": f"env-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": measured_traffic(args.envs_per_gpu, args.rays, args.cars, args.policy, args.steps),
                          "kernel": env.kernel_name(), "kernel_ms_per_launch": kernel_s * 1e3,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "frac_of_measured_copy_6290": achieved / HBM_MEASURED_COPY_GBS,

@@ -260,7 +260,11 @@ __device__ __forceinline__ void lidar_sweep(const DeviceParams& P, const LdsView
     const int lane = lane_id();
     const unsigned char* lds_base = reinterpret_cast<const unsigned char*>(L.veh) - P.off_veh;
     const uint2* rank = L.rank;
-    const uint8_t* __restrict__ field = P.field;
+    // the pointers come out of the LDS parameter block: tell the compiler they are global (global_load / global_store, not flat)
+    typedef const __attribute__((address_space(1))) uint8_t* global_u8;
+    typedef __attribute__((address_space(1))) float* global_f32;
+    const global_u8 field = (global_u8)P.field;
+    const global_f32 out_g = (global_f32)out_global;
     const int W = P.width;
     for (int base = 0; base < R; base += FTGP_WAVE * FTGP_RPL) {
         Ray ray[FTGP_RPL];
@@ -325,7 +329,7 @@ __device__ __forceinline__ void lidar_sweep(const DeviceParams& P, const LdsView
                         if (rc < INFINITY && (r < 0.0f || rc < r)) r = rc;
                     }
                 }
-                out_global[j] = r;
+                out_g[j] = r;
                 if (out_lds) {      // the on-device driver only reads ranges[0] and ranges[eighth : n - eighth]
                     if (j == 0) out_lds[0] = r;
                     if (j >= P.eighth && j < R - P.eighth) out_lds[1 + j - P.eighth] = r;

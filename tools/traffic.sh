@@ -9,7 +9,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python3 - <<PY
 import csv,glob,json
-out={"config":"4096 envs x 1080 rays, fast, $STEPS steps per launch","steps":$STEPS,"n_envs":4096}
+out={"config":"4096 envs x 1080 rays, fast, $STEPS steps per launch","steps":$STEPS,"n_envs":4096,"n_rays":1080,"cars":1,"policy":"fast"}
 for c in ("FETCH_SIZE","WRITE_SIZE"):
     f=glob.glob(f"gpurun_out/pmc_{c}/**/*counter_collection.csv",recursive=True)[0]
     rows=[r for r in csv.DictReader(open(f)) if "ftgp_step_kernel" in r["Kernel_Name"] and r["Counter_Name"]==c]
