@@ -330,3 +330,27 @@ def test_both_acceleration_structures_return_the_same_bits(product, oracle, monk
         np.testing.assert_array_equal(a.pose(), b.pose())
         np.testing.assert_array_equal(a.progress(), b.progress())
         assert_same_state(a, o); assert_same_state(b, o)
+
+
+def test_config2_and_config5_full_size_properties(product, oracle):
+    """BASELINE.json configs[1] (1024 envs, circle, nidc) and configs[4] (4096 envs x 4 cars) at full size:
+    launch-split invariance (a checksum of everything), range sanity, and the oracle on a prefix of the envs."""
+    for name, kw, policy, steps, prefix in (
+            ("circle", dict(n_envs=1024, n_rays=1080, spawn_mode=1, seed=1234), "nidc", 150, 16),
+            ("track", dict(n_envs=4096, cars_per_env=4, n_rays=1080, spawn_mode=0, seed=1234, lap_target=3), "fast", 60, 4)):
+        t = load_track(name)
+        okw = dict(kw, n_envs=prefix)
+        with capi.Env(product, t, **kw) as g, capi.Env(product, t, **kw) as g2, capi.Env(oracle, t, **okw) as o:
+            oracle.dll.oracle_set_threads(o.h, 8)
+            g.rollout(policy, steps); g2.rollout(policy, steps // 3); g2.rollout(policy, steps - steps // 3); o.rollout(policy, steps)
+            r = g.lidar()
+            np.testing.assert_array_equal(r, g2.lidar())
+            np.testing.assert_array_equal(g.pose(), g2.pose())
+            np.testing.assert_array_equal(g.progress(), g2.progress())
+            assert ((r == -1) | ((r >= 0) & (r < 60))).all()
+            n = prefix * kw.get("cars_per_env", 1)
+            np.testing.assert_array_equal(r[:n], o.lidar())
+            np.testing.assert_array_equal(g.progress()[:n], o.progress())
+            np.testing.assert_allclose(g.pose()[:n], o.pose(), rtol=0, atol=TOL)
+            m = g.metrics_local()
+            assert m[0] == kw["n_envs"] * steps and m[1] == g.n_cars
