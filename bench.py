@@ -42,6 +42,14 @@ def measured_traffic(n_envs, n_rays, cars, policy, steps):
     return t["traffic_bytes_per_env_step"] * n_envs * steps
 
 
+def _try(fn):
+    try:
+        fn()
+        return None
+    except Exception as exc:      # noqa: BLE001 - reported by the caller
+        return exc
+
+
 def cpu_baseline(track, n_rays, policy, cars, seed):
     """The CPU oracle ("port") on a bounded sample of the same workload, on this host's cores (rank 0, N = 1 only)."""
     from tests.helpers import load_oracle
@@ -107,17 +115,26 @@ def main():
         try:
             if world > n_dev:
                 raise RuntimeError("more ranks than GPUs: RCCL refuses two ranks on one device")
+            if os.environ.get("FTGP_BENCH_COLLECTIVE", "rccl") != "rccl":
+                raise RuntimeError("FTGP_BENCH_COLLECTIVE requests the gloo gather")
             uid = [capi.comm_unique_id(lib) if rank == 0 else None]
             dist.broadcast_object_list(uid, src=0)
-            env.comm_init(uid[0], rank, world)
-        except Exception as exc:   # rehearsal on a box with fewer GPUs than ranks: keep going over gloo, and say so
+            # watchdog: a stalled RCCL bootstrap must not hang the scaling run
+            import threading
+            box = {}
+            th = threading.Thread(target=lambda: box.setdefault("err", _try(lambda: env.comm_init(uid[0], rank, world))), daemon=True)
+            th.start(); th.join(timeout=float(os.environ.get("FTGP_RCCL_INIT_TIMEOUT", "180")))
+            if th.is_alive():
+                raise RuntimeError("ncclCommInitRank did not return in time")
+            if box.get("err") is not None:
+                raise box["err"]
+        except Exception as exc:   # rehearsal on a box with fewer GPUs than ranks, or an RCCL problem: keep going over gloo, and say so
             ok = 0
-            if world <= n_dev:
-                print(f"[rank {rank}] RCCL communicator failed ({exc}); using the gloo gather", file=sys.stderr)
+            print(f"[rank {rank}] RCCL communicator not used ({exc}); metrics go over the gloo gather", file=sys.stderr)
         flag = torch.tensor([ok]); dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag[0]) == 0:
             gloo_gather = ftdist.GlooGather()
-            collective = "gloo all_gather (RCCL communicator unavailable: ranks > GPUs)"
+            collective = "gloo all_gather (RCCL communicator not used, see stderr)"
 
     def gather():
         if gloo_gather is not None:
@@ -180,10 +197,12 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(track, args.rays, args.policy, args.cars, seed)
         print(json.dumps(out), flush=True)
-    env.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if gloo_gather is not None and world <= n_dev:
+        os._exit(0)            # a stalled RCCL thread may still hold the handle: do not wait for it
+    env.close()
 
 
 if __name__ == "__main__":

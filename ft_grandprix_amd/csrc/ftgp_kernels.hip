@@ -323,8 +323,16 @@ __device__ __forceinline__ void lidar_sweep(const DeviceParams& P, const LdsView
             if (j < R) {
                 float r = ray[q].result;
                 if (MULTI) {
+                    // conservative cull before the exact box / puck tests: every visible part of a car lies within 0.114 of
+                    // its origin (chassis corner 0.1137, puck 0.0825), so a car whose origin is farther than 0.125 from the
+                    // ray, behind its start, or beyond the wall hit cannot change the range.  Results are unaffected.
+                    const float ox = (float)lcx - r0 * dxw[q], oy = (float)lcy - r0 * dyw[q];
                     for (int k = 0; k < P.cars_per_env; ++k) {
                         if (k == my_slot || env_cars[k].finished) continue;      // shadowed cars are invisible (custom.py:1441-1466)
+                        const float wx = (float)env_cars[k].x - ox, wy = (float)env_cars[k].y - oy;
+                        const float along = wx * dxw[q] + wy * dyw[q];
+                        const float perp2 = (wx * wx + wy * wy) - along * along;
+                        if (perp2 > 0.125f * 0.125f || along < -0.125f || (r >= 0.0f && along - 0.125f > r)) continue;
                         const float rc = ray_vs_car(v, env_cars + k, lcx, lcy, dxw[q], dyw[q]);
                         if (rc < INFINITY && (r < 0.0f || rc < r)) r = rc;
                     }
