@@ -362,7 +362,9 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
     // cars (waves) per workgroup: as many as fit the 160 KiB of LDS next to the track, at most 16 (one workgroup per CU)
     {
         const int unit = e->multi ? cfg->cars_per_env : 1;
-        int want = 16;
+        // multi-car envs synchronise with workgroup barriers twice per step: with the flat field (no per-workgroup track copy
+        // in LDS) one env per workgroup keeps that wait among the cars that actually interact (measured: -14 %)
+        int want = (e->multi && P.use_field) ? unit : 16;
         if (const char* sv = getenv("FTGP_CARS_PER_BLOCK")) { const int c = atoi(sv); if (c >= 1 && c <= 16) want = c; }
         // small batches: fewer cars per workgroup so that every CU gets work (256 CUs)
         const int n_units = P.n_cars / unit;
