@@ -176,6 +176,7 @@ int lds_layout(DeviceParams& P, int cpb)
     P.off_coarse = o; o += P.use_field ? 0 : pad16(((size_t)P.nbx * P.nby + 1) / 2);
     P.off_ray = o;    o += 2 * P.ray_floats * (int)sizeof(float);
     P.off_state = o;  o += cpb * (int)sizeof(CarCore);
+    P.off_next = o;   o += pad16((size_t)cpb * sizeof(Dyn));
     P.off_scan = o;   o += cpb * P.scan_floats * (int)sizeof(float);
     P.lds_bytes = o;
     return o;

@@ -43,7 +43,7 @@ struct DeviceParams {
     const uint2* rank;            // [nby][nwpr] {non-empty bits of 32 blocks, number of non-empty blocks before this word}
     const uint8_t* fine;          // [n_fine][32] 4 bits per pixel of each non-empty block: chessboard distance in PIXELS to the nearest wall pixel
     // LDS layout of the step kernel (byte offsets, all 16-B aligned)
-    int32_t off_params, off_veh, off_fine, off_rank, off_path, off_coarse, off_ray, off_state, off_scan, lds_bytes;
+    int32_t off_params, off_veh, off_fine, off_rank, off_path, off_coarse, off_ray, off_state, off_next, off_scan, lds_bytes, pad5;
     int32_t eighth, scan_floats, ray_floats;   // int(n_rays / 8); floats per LDS scan = 1 + (n_rays - 2*eighth) padded to 4; padded ray table
     float snap_eps, pad3;         // the march re-checks a landing point with the exact comparisons within this distance of a pixel boundary
     const uint8_t* field;         // flat per-pixel chessboard distance to the nearest wall pixel (0 = wall, clamp 255), [height][width], HBM/L2

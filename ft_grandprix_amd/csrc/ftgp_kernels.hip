@@ -425,6 +425,7 @@ __device__ __forceinline__ void progress_wave(const DeviceParams& P, const doubl
 // =============================================================================================
 struct Force { double fx, fy, tz; };
 struct Dyn { double x, y, qw, qz, vx, vy, wz, qs, qsd, w[4]; };
+static_assert(sizeof(Dyn) == 104 && offsetof(CarCore, w) == offsetof(Dyn, w) && offsetof(CarCore, qsd) == offsetof(Dyn, qsd), "Dyn must mirror the head of CarCore");
 
 // Chassis circles against wall pixels: the (2nx+1) x (2ny+1) candidate cells of each circle are tested
 // one per lane; the deepest penetration (ties: first in raster order) is picked by a wave reduction.
@@ -533,8 +534,10 @@ __device__ __forceinline__ void car_contact(const DeviceParams& P, const LdsView
 }
 
 // new dynamic state from the pre-step state in LDS (other cars of the env are read pre-step too)
+// The result goes to `out` in LDS (written by lane 0): a by-value return of a non-inlined function would travel through
+// scratch memory for all 64 lanes.  Dyn is layout-compatible with the head of CarCore.
 template <bool MULTI, bool GF>
-__device__ __attribute__((noinline)) Dyn integrate(const DeviceParams& P, const LdsView& L, const CarCore* st, const CarCore* env_cars, int my_slot)
+__device__ __attribute__((noinline)) void integrate(const DeviceParams& P, const LdsView& L, const CarCore* st, const CarCore* env_cars, int my_slot, Dyn* out)
 {
     const FtgpVehicle& v = L.veh->v;
     const double dt = P.dt;
@@ -595,7 +598,7 @@ __device__ __attribute__((noinline)) Dyn integrate(const DeviceParams& P, const 
     o.x = s.x + dt * o.vx;
     o.y = s.y + dt * o.vy;
     o.qw = nw / n; o.qz = nz / n;
-    return o;
+    if (lane_id() == 0) *out = o;
 }
 
 __device__ __forceinline__ void dyn_store(const Dyn& o, CarCore* st)
@@ -607,9 +610,7 @@ __device__ __forceinline__ void dyn_store(const Dyn& o, CarCore* st)
 // =============================================================================================
 // K5: on-device drivers.  nidc.py:12-131 / fast.py:11-139 restated for one wave; the previous scan sits in LDS.
 // =============================================================================================
-struct Ctrl { double speed, steer, last_steer; };
-
-__device__ __attribute__((noinline)) void policy_disparity(const DeviceParams& P, float* __restrict__ scan, Ctrl& ctl, bool fast)
+__device__ __attribute__((noinline)) void policy_disparity(const DeviceParams& P, float* __restrict__ scan, CarCore* st, bool fast)
 {
     const int lane = lane_id();
     const int n = P.n_rays;
@@ -675,37 +676,38 @@ __device__ __attribute__((noinline)) void policy_disparity(const DeviceParams& P
     const double lim = 90.0 * (M_PI / 180.0);
     if (ang < -lim) ang = -lim;
     if (ang > lim) ang = lim;
-    double speed;
+    double speed, last = st->last_steer;
     if (!fast) {
         speed = 0.5 * 5 * (1 - fabs(ang) / (1.57 * 2));             // nidc.py:130
     } else {
         const double old = 0.0;                                     // fast.py:131-133
-        ang = ctl.last_steer * old + ang * (1 - old);
-        ctl.last_steer = ang;
+        ang = st->last_steer * old + ang * (1 - old);
+        last = ang;
         if (fabs(ang) < 0.1 && (double)range0 > 0.5) speed = 7.0;   // fast.py:135-138
         else { const double sp = 0.5 * 5 * (1 - fabs(ang) / M_PI); speed = sp < 2.0 ? sp : 2.0; }
     }
-    ctl.speed = speed; ctl.steer = ang;
+    if (lane_id() == 0) { st->u_speed = speed; st->u_steer = ang; st->last_steer = last; }
 }
 
 // evaluates the driver of car ci and stores the controls into its state record
 __device__ __forceinline__ void policy_apply(const DeviceParams& P, int policy, float* scan, CarCore* st, int ci, int64_t steps)
 {
-    Ctrl c; c.speed = st->u_speed; c.steer = st->u_steer; c.last_steer = st->last_steer;
-    if (st->finished) { c.speed = 0.0; c.steer = 0.0; }             // finished cars get the null driver (custom.py:1446)
-    else switch (policy) {
-    case FTGP_POLICY_LOBOTOMY: c.speed = 0.0; c.steer = 0.0; break;   // lobotomy.py:2-3
-    case FTGP_POLICY_NIDC: policy_disparity(P, scan, c, false); break;
-    case FTGP_POLICY_FAST: policy_disparity(P, scan, c, true); break;
+    const bool lane0 = lane_id() == 0;
+    if (st->finished) {                                             // finished cars get the null driver (custom.py:1446)
+        if (lane0) { st->u_speed = 0.0; st->u_steer = 0.0; }
+        return;
+    }
+    switch (policy) {
+    case FTGP_POLICY_LOBOTOMY: if (lane0) { st->u_speed = 0.0; st->u_steer = 0.0; } break;   // lobotomy.py:2-3
+    case FTGP_POLICY_NIDC: policy_disparity(P, scan, st, false); break;
+    case FTGP_POLICY_FAST: policy_disparity(P, scan, st, true); break;
     case FTGP_POLICY_RANDOM: {
         uint64_t h = splitmix64(P.seed + (uint64_t)((long)P.env_base * P.cars_per_env + ci) * 0x9E3779B97F4A7C15ull);
         h = splitmix64(h ^ (uint64_t)steps);
-        c.speed = 3.0 * u01(h);
-        c.steer = 2.0 * u01(splitmix64(h)) - 1.0;
+        if (lane0) { st->u_speed = 3.0 * u01(h); st->u_steer = 2.0 * u01(splitmix64(h)) - 1.0; }
         break; }
     default: break;
     }
-    if (lane_id() == 0) { st->u_speed = c.speed; st->u_steer = c.steer; st->last_steer = c.last_steer; }
 }
 
 // =============================================================================================
@@ -790,15 +792,18 @@ __global__ void __launch_bounds__(1024) ftgp_step_kernel(const DeviceParams* __r
             lidar_sweep<MULTI, GF>(P, L, st, my_ranges, scan, env_cars, my_slot);   // sensors at the pre-integration pose
 #endif
         }
-        Dyn nxt;
+        // single-car envs: nobody else reads this record, K1 commits in place; multi-car: into a staging slot, committed
+        // after every car of the env has read the pre-step states
+        Dyn* nxt = MULTI ? reinterpret_cast<Dyn*>(lds + P.off_next) + wave : reinterpret_cast<Dyn*>(st);
 #ifndef FTGP_ABLATE_K1
-        if (live) nxt = integrate<MULTI, GF>(P, L, st, env_cars, my_slot);
-#else
-        if (live) { nxt.x = st->x; nxt.y = st->y; nxt.qw = st->qw; nxt.qz = st->qz; nxt.vx = st->vx; nxt.vy = st->vy; nxt.wz = st->wz; nxt.qs = st->qs; nxt.qsd = st->qsd; nxt.w[0] = st->w[0]; nxt.w[1] = st->w[1]; nxt.w[2] = st->w[2]; nxt.w[3] = st->w[3]; }
+        if (live) integrate<MULTI, GF>(P, L, st, env_cars, my_slot, nxt);
 #endif
         if (MULTI) __syncthreads();          // every car of the env has read the pre-step states
         if (live) {
-            if (lane == 0) dyn_store(nxt, st);
+            if (MULTI) {
+                wave_lds_sync();
+                if (lane < (int)(sizeof(Dyn) / 4)) reinterpret_cast<uint32_t*>(st)[lane] = reinterpret_cast<const uint32_t*>(nxt)[lane];
+            }
             wave_lds_sync();
             steps += 1;
 #ifndef FTGP_ABLATE_K3
