@@ -1,16 +1,20 @@
 // ftgp_kernels.hip -- HIP kernels of the ft_grandprix hot path for gfx950 (CDNA4, wave64).
 //
-//   ftgp_step_kernel   K5 driver -> K2 LiDAR sweep -> K1 integrate -> K3 lap progress, n_steps per launch.
-//       One workgroup per CU (up to 16 waves), one wave per car, persistent over all steps of the launch.
-//       Everything a step touches repeatedly is staged into LDS once per launch with coalesced 16-B loads:
-//       the track as a two-level grid over 8x8-pixel blocks (block distance field + rank table + 64-bit
-//       wall masks, ~60 KB), the centre-line, the ray table, each car's state record and its previous scan.
-//       The 64 lanes of a wave stride the car's rays (256-B coalesced range stores, the only per-step HBM
-//       traffic); contact candidates and the centre-line argmin are spread over lanes and resolved with
-//       wave-level min/max reductions; the driver's disparity masks come from wave ballots.
+//   ftgp_step_kernel<MULTI, GF>   K5 driver -> K2 LiDAR sweep -> K1 integrate -> K3 lap progress, n_steps per launch.
+//       One wave per car, up to 16 waves per workgroup, persistent over all steps of the launch.  Staged into LDS once
+//       per launch with coalesced 16-B loads: the parameter block, vehicle constants, centre-line, ray table, each car's
+//       state record and the scan window the driver reads.  The 64 lanes of a wave stride the car's rays (aligned 256-B
+//       range stores, the only per-step HBM traffic besides scratch); contact candidates and the centre-line argmin are
+//       spread over lanes and resolved with wave-level min/max reductions; the driver's disparity masks come from wave
+//       ballots.  The march skips wall-free cells with one of two interchangeable structures (template flag GF):
+//         GF = true  : flat per-pixel chessboard distance field, one byte per pixel, read from L2 (default)
+//         GF = false : two-level grid over 8x8-pixel blocks staged in LDS (4-bit block distances, 4-bit pixel distances
+//                      of non-empty blocks behind a rank table)
+//       Both return the bits of the plain-DDA specification.
 //   ftgp_policy_kernel    K5 alone (ftgp_policy_eval).
 //   ftgp_reset_kernel     K4 reset / spawn (+ K3 at the spawn pose), one car per lane.
 //   ftgp_progress_kernel  K3 alone (after ftgp_set_pose), one car per lane.
+//   ftgp_fakelidar_kernel raycast.fakelidar restated, one ray per lane.
 //   ftgp_metrics_kernel   per-GPU metrics record.
 //
 // Reference behaviour restated by each block is cited inline (paths relative to the reference repo).
@@ -599,12 +603,6 @@ __device__ __attribute__((noinline)) void integrate(const DeviceParams& P, const
     o.y = s.y + dt * o.vy;
     o.qw = nw / n; o.qz = nz / n;
     if (lane_id() == 0) *out = o;
-}
-
-__device__ __forceinline__ void dyn_store(const Dyn& o, CarCore* st)
-{
-    st->x = o.x; st->y = o.y; st->qw = o.qw; st->qz = o.qz; st->vx = o.vx; st->vy = o.vy; st->wz = o.wz;
-    st->qs = o.qs; st->qsd = o.qsd; st->w[0] = o.w[0]; st->w[1] = o.w[1]; st->w[2] = o.w[2]; st->w[3] = o.w[3];
 }
 
 // =============================================================================================

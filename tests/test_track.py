@@ -1,0 +1,75 @@
+"""Asset front-end (ft_grandprix_amd/track.py): SVG path sampling semantics, bit packing, frames, synthetic track."""
+import numpy as np
+import pytest
+
+from ft_grandprix_amd import track as tr
+
+
+def test_pack_bits_roundtrip_and_word_layout():
+    rng = np.random.default_rng(0)
+    wall = rng.random((37, 70)) < 0.2
+    bits = tr.pack_bits(wall)
+    assert bits.shape == (37, 3) and bits.dtype == np.uint32
+    t = tr.build_track(wall, np.zeros((100, 2)), "x")
+    np.testing.assert_array_equal(t.wall_mask(), wall)
+    y, x = 5, 41
+    assert bool((bits[y, x >> 5] >> (x & 31)) & 1) == bool(wall[y, x])     # bit (x & 31) of word x >> 5, include/ftgp.h
+
+
+def test_wall_frames():
+    # mushr.em.xml:17-20,55,92: tiles centred on (size_x*cx, -size_y*cy) -> pixel column 0 starts at -size_x/2
+    sx, sy, ox, oy, hc, vc = tr.wall_frame(1600, 1600, "mjcf")
+    assert (hc, vc) == (80, 80) and sx == sy == 0.025 and ox == -0.25 and oy == 0.25
+    sx, sy, ox, oy, hc, vc = tr.wall_frame(2133, 1600, "mjcf")
+    assert (hc, vc) == (107, 80) and sx == pytest.approx(40 / 2140) and ox == pytest.approx(-20 / 107)
+    sx, sy, ox, oy, _, _ = tr.wall_frame(2133, 1600, "pixel")         # custom.py:1185-1186, 1382-1384
+    assert sx == 40 / 2133 and sy == 40 / 1600 and ox == oy == 0
+
+
+def test_svg_path_semantics():
+    # Path.point(t): segments weighted by arc length, linear local parameter; Move has length 0; Close is a line
+    seg = tr.parse_svg_path("m 10,10 l 30,0 0,10 z")           # lengths 30, 10, then the closing line sqrt(30^2+10^2)
+    assert [type(s).__name__ for s in seg] == ["_Move", "_Line", "_Line", "_Line"]
+    pts = tr.sample_path_points(seg, 4)
+    total = 30 + 10 + np.hypot(30, 10)
+    np.testing.assert_allclose(pts[0], [10, 10])
+    s1 = 0.25 * total                                          # still on the first line
+    np.testing.assert_allclose(pts[1], [10 + s1, 10])
+    # relative cubic: control points are relative to the segment start (SVG 'c')
+    seg = tr.parse_svg_path("M 0,0 c 0,10 10,10 10,0 C 10,-10 20,-10 20,0")
+    assert seg[1].c1 == 10j and seg[1].end == 10 and seg[2].start == 10 and seg[2].end == 20
+    p = tr.sample_path_points(seg, 2)
+    np.testing.assert_allclose(p[1], [10, 0], atol=1e-9)       # half the arc length = the joint of two mirror-image cubics
+    # smooth cubic reflects the previous control point
+    seg = tr.parse_svg_path("M 0,0 C 0,5 5,5 5,0 S 10,-5 10,0")
+    assert seg[2].c1 == complex(5, -5)
+    with pytest.raises(NotImplementedError):
+        tr.parse_svg_path("M 0,0 A 5,5 0 0 1 10,10")
+
+
+def test_cubic_length_matches_fine_polyline():
+    c = tr._Cubic(0j, 30 + 40j, 60 - 40j, 100 + 0j)
+    t = np.linspace(0, 1, 200001)
+    z = (1 - t) ** 3 * c.start + 3 * (1 - t) ** 2 * t * c.c1 + 3 * (1 - t) * t ** 2 * c.c2 + t ** 3 * c.end
+    assert c.length() == pytest.approx(np.abs(np.diff(z)).sum(), rel=1e-9)
+
+
+def test_bundled_tracks_are_closed_loops_on_the_road():
+    from scipy.ndimage import distance_transform_edt
+    for name in ("track", "circle", "small-circle", "inkscape"):
+        t = tr.load_track(name)
+        assert t.path.shape == (100, 2) and len(t.chunks) == tr.chunk_metadata(t.wall_mask(), name)["chunks"].__len__()
+        edt = distance_transform_edt(~t.wall_mask())
+        px, py = t.path[:, 0] / 40 * t.width, -t.path[:, 1] / 40 * t.height
+        assert edt[py.astype(int), px.astype(int)].min() > 8          # centre-line stays clear of the walls
+        seg = np.hypot(*(np.roll(t.path, -1, axis=0) - t.path).T)
+        assert seg.max() < 1.3                                        # closed: the wrap-around segment is as short as the others
+
+
+def test_synthetic_oval_runs_through_the_oracle(oracle):
+    from ft_grandprix_amd import capi
+    t = tr.synthetic_oval(640, 480, half_width_px=20)
+    with capi.Env(oracle, t, n_envs=4, n_rays=90, spawn_mode=1) as e:
+        e.rollout("nidc", 400)
+        r = e.lidar()
+        assert (r > 0).mean() > 0.95 and np.abs(e.pose()[:, 7:9]).max() > 0.3
