@@ -242,9 +242,16 @@ __device__ __forceinline__ float ray_vs_car(const FtgpVehicle& v, const CarCore*
 // Full sweep of one car by one wave.  Rangefinder geometry: template/mushr.em.xml:98-117 -- ray j leaves
 // the ring at centre - 0.03*dir_j, dir_j = R(yaw) * (sin phi_j, -cos phi_j); j = 0 is the rear, CCW.
 // Values replace data.sensordata[vehicle_state.sensors] (custom.py:1395).
-// Each lane marches FTGP_RPL rays at once (rays j, j + 64, ... of a 64*RPL group) in one wave-uniform loop.
-#ifndef FTGP_RPL
-#define FTGP_RPL 1
+//
+// Scheduling: the 64 lanes work through the car's rays in index order, but a "pass" does not wait for its slowest
+// ray: as soon as FTGP_REFILL lanes are free, they take the next rays (rank among the free lanes via ballot/popcount,
+// one batched ray_init for all of them) while the unfinished rays simply carry on.  On the headline workload this cuts
+// the wave-iterations per car from 245 (sum of per-pass maxima) to ~170 (ideal 135); which lane marches which ray has no
+// influence on any result.
+// measured on MI355X (tools/sweep_refill.sh): 24 free lanes for single-car envs, 48 for multi-car envs (their refill
+// block also runs the inter-vehicle tests); 64 would be the classic "wait for the slowest ray" pass
+#ifndef FTGP_REFILL
+#define FTGP_REFILL (MULTI ? 48 : 24)
 #endif
 template <bool MULTI, bool GF>
 __device__ __forceinline__ void lidar_sweep(const DeviceParams& P, const LdsView& L, const CarCore* st, float* __restrict__ out_global,
@@ -262,6 +269,7 @@ __device__ __forceinline__ void lidar_sweep(const DeviceParams& P, const LdsView
     const float r0 = (float)v.lidar_ring_radius;
     const int R = P.n_rays;
     const int lane = lane_id();
+    const uint64_t lanes_below = (1ull << lane) - 1ull;
     const unsigned char* lds_base = reinterpret_cast<const unsigned char*>(L.veh) - P.off_veh;
     const uint2* rank = L.rank;
     // the pointers come out of the LDS parameter block: tell the compiler they are global (global_load / global_store, not flat)
@@ -270,83 +278,79 @@ __device__ __forceinline__ void lidar_sweep(const DeviceParams& P, const LdsView
     const global_u8 field = (global_u8)P.field;
     const global_f32 out_g = (global_f32)out_global;
     const int W = P.width;
-    for (int base = 0; base < R; base += FTGP_WAVE * FTGP_RPL) {
-        Ray ray[FTGP_RPL];
-        float dxw[FTGP_RPL], dyw[FTGP_RPL];
-        #pragma unroll
-        for (int q = 0; q < FTGP_RPL; ++q) {
-            const int j = base + q * FTGP_WAVE + lane;
-            const bool valid = j < R;
-            const int jj = valid ? j : 0;
-            const float bx = L.ray_bx[jj], by = L.ray_by[jj];
-            dxw[q] = fmaf(chf, bx, -(shf * by));
-            dyw[q] = fmaf(shf, bx, chf * by);
-            const float du = dxw[q] * isx;
-            const float dv = -(dyw[q] * isy);
-            const float pu = fmaf(du, -r0, u0);
-            const float pv = fmaf(dv, -r0, v0);
-            ray_init(P, ray[q], pu, pv, du, dv, valid);
+
+    Ray ray; ray.active = false; ray.result = -1.0f; ray.s = 0.0f;
+    ray.pum = ray.pvm = ray.dum = ray.dvm = ray.ivx = ray.ivy = 0.0f; ray.ix = ray.iy = ray.mx = ray.my = 0;
+    float dxw = 0.0f, dyw = 0.0f;
+    int j = -1;              // the ray this lane is marching (or has just finished); -1: none
+    int next = 0;            // first ray not handed out yet (wave-uniform)
+    for (int round = 0; round < 4 * 8192; ++round) {
+        // ---- lanes whose ray is finished: store its range, then take the next ray in index order
+        const bool idle = !ray.active;
+        if (idle && j >= 0) {
+            float r = ray.result;
+            if (MULTI) {
+                // conservative cull before the exact box / puck tests: every visible part of a car lies within 0.114 of
+                // its origin (chassis corner 0.1137, puck 0.0825), so a car whose origin is farther than 0.125 from the
+                // ray, behind its start, or beyond the wall hit cannot change the range.  Results are unaffected.
+                const float ox = (float)lcx - r0 * dxw, oy = (float)lcy - r0 * dyw;
+                for (int k = 0; k < P.cars_per_env; ++k) {
+                    if (k == my_slot || env_cars[k].finished) continue;      // shadowed cars are invisible (custom.py:1441-1466)
+                    const float wx = (float)env_cars[k].x - ox, wy = (float)env_cars[k].y - oy;
+                    const float along = wx * dxw + wy * dyw;
+                    const float perp2 = (wx * wx + wy * wy) - along * along;
+                    if (perp2 > 0.125f * 0.125f || along < -0.125f || (r >= 0.0f && along - 0.125f > r)) continue;
+                    const float rc = ray_vs_car(v, env_cars + k, lcx, lcy, dxw, dyw);
+                    if (rc < INFINITY && (r < 0.0f || rc < r)) r = rc;
+                }
+            }
+            out_g[j] = r;
+            if (out_lds) {      // the on-device driver only reads ranges[0] and ranges[eighth : n - eighth]
+                if (j == 0) out_lds[0] = r;
+                if (j >= P.eighth && j < R - P.eighth) out_lds[1 + j - P.eighth] = r;
+            }
+            j = -1;
         }
+        const uint64_t idle_mask = __ballot(idle);
+        if (next < R) {
+            const int mine = next + __popcll(idle_mask & lanes_below);
+            if (idle && mine < R) {
+                j = mine;
+                const float bx = L.ray_bx[j], by = L.ray_by[j];
+                dxw = fmaf(chf, bx, -(shf * by));
+                dyw = fmaf(shf, bx, chf * by);
+                const float du = dxw * isx;
+                const float dv = -(dyw * isy);
+                const float pu = fmaf(du, -r0, u0);
+                const float pv = fmaf(dv, -r0, v0);
+                ray_init(P, ray, pu, pv, du, dv, true);
+            }
+            next += __popcll(idle_mask);
+        }
+        const uint64_t live_mask = __ballot(ray.active);
+        if (live_mask == 0) {
+            if (next >= R && !__any(j >= 0)) break;      // nothing marching, nothing to store, nothing left to hand out
+            continue;                                    // e.g. rays that started outside the image: store them and refill
+        }
+        // ---- march until enough lanes are free to make a batched refill worthwhile (or, at the end, until all are done)
+        const int want_free = (next < R) ? FTGP_REFILL : FTGP_WAVE;
         for (int guard = 0; guard < 8192; ++guard) {
-            bool any_active = false;
-            #pragma unroll
-            for (int q = 0; q < FTGP_RPL; ++q) any_active |= ray[q].active;
-            if (!__any(any_active)) break;
-            int t[FTGP_RPL], cur[FTGP_RPL], hi[FTGP_RPL], xhi[FTGP_RPL], yhi[FTGP_RPL]; bool stepx[FTGP_RPL], near[FTGP_RPL];
-            uint2 rk[FTGP_RPL]; Probe pb[FTGP_RPL]; unsigned b2[FTGP_RPL];
+            Probe pb; unsigned b2;
             if (GF) {
                 // flat per-pixel field from L2: one byte, no indirection (pixel-distance semantics for every cell)
-                #pragma unroll
-                for (int q = 0; q < FTGP_RPL; ++q) {
-                    const int tx = ray[q].ix ^ ray[q].mx, ty = ray[q].iy ^ ray[q].my;
-                    pb[q].nonempty = true; pb[q].shift2 = 0; pb[q].addr2 = 0;
-                    b2[q] = field[ty * W + tx];
-                }
+                const int tx = ray.ix ^ ray.mx, ty = ray.iy ^ ray.my;
+                pb.nonempty = true; pb.shift2 = 0; pb.addr2 = 0;
+                b2 = field[ty * W + tx];
             } else {
-                #pragma unroll
-                for (int q = 0; q < FTGP_RPL; ++q) rk[q] = rank[ray_rank_addr(P, ray[q])];          // stage 1: all rays' rank words in flight
-                #pragma unroll
-                for (int q = 0; q < FTGP_RPL; ++q) { pb[q] = ray_probe(P, ray[q], rk[q]); b2[q] = lds_base[pb[q].addr2]; }   // stage 2
+                const uint2 rk = rank[ray_rank_addr(P, ray)];
+                pb = ray_probe(P, ray, rk);
+                b2 = lds_base[pb.addr2];
             }
-            bool any_near = false;
-            #pragma unroll
-            for (int q = 0; q < FTGP_RPL; ++q) {
-                near[q] = ray_step(P, ray[q], pb[q], b2[q], GF ? 255 : 15, t[q], cur[q], hi[q], stepx[q], xhi[q], yhi[q]);
-                any_near |= near[q];
-            }
-            if (__any(any_near)) {
-                #pragma unroll
-                for (int q = 0; q < FTGP_RPL; ++q) { const int tf = ray_fix(ray[q], t[q], cur[q], hi[q], stepx[q]); t[q] = near[q] ? tf : t[q]; }
-            }
-            #pragma unroll
-            for (int q = 0; q < FTGP_RPL; ++q) ray_commit(P, ray[q], t[q], cur[q], stepx[q], xhi[q], yhi[q]);
-        }
-        #pragma unroll
-        for (int q = 0; q < FTGP_RPL; ++q) {
-            const int j = base + q * FTGP_WAVE + lane;
-            if (j < R) {
-                float r = ray[q].result;
-                if (MULTI) {
-                    // conservative cull before the exact box / puck tests: every visible part of a car lies within 0.114 of
-                    // its origin (chassis corner 0.1137, puck 0.0825), so a car whose origin is farther than 0.125 from the
-                    // ray, behind its start, or beyond the wall hit cannot change the range.  Results are unaffected.
-                    const float ox = (float)lcx - r0 * dxw[q], oy = (float)lcy - r0 * dyw[q];
-                    for (int k = 0; k < P.cars_per_env; ++k) {
-                        if (k == my_slot || env_cars[k].finished) continue;      // shadowed cars are invisible (custom.py:1441-1466)
-                        const float wx = (float)env_cars[k].x - ox, wy = (float)env_cars[k].y - oy;
-                        const float along = wx * dxw[q] + wy * dyw[q];
-                        const float perp2 = (wx * wx + wy * wy) - along * along;
-                        if (perp2 > 0.125f * 0.125f || along < -0.125f || (r >= 0.0f && along - 0.125f > r)) continue;
-                        const float rc = ray_vs_car(v, env_cars + k, lcx, lcy, dxw[q], dyw[q]);
-                        if (rc < INFINITY && (r < 0.0f || rc < r)) r = rc;
-                    }
-                }
-                out_g[j] = r;
-                if (out_lds) {      // the on-device driver only reads ranges[0] and ranges[eighth : n - eighth]
-                    if (j == 0) out_lds[0] = r;
-                    if (j >= P.eighth && j < R - P.eighth) out_lds[1 + j - P.eighth] = r;
-                }
-            }
+            int t, cur, hi, xhi, yhi; bool stepx;
+            const bool near = ray_step(P, ray, pb, b2, GF ? 255 : 15, t, cur, hi, stepx, xhi, yhi);
+            if (__any(near)) { const int tf = ray_fix(ray, t, cur, hi, stepx); t = near ? tf : t; }
+            ray_commit(P, ray, t, cur, stepx, xhi, yhi);
+            if (__popcll(__ballot(!ray.active)) >= want_free) break;
         }
     }
 }
