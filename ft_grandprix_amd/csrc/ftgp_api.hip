@@ -343,6 +343,8 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
     P.snap_eps = 1.0f / 512.0f;
     P.use_field = 1;                                                // default: flat per-pixel field from L2 (fewest instructions per march iteration)
     if (const char* sv = getenv("FTGP_FIELD")) { if (!strcmp(sv, "lds")) P.use_field = 0; else if (!strcmp(sv, "global")) P.use_field = 1; }
+    P.scan_full = P.use_field;                                      // LDS has room for whole rows only without the wall grid
+    if (P.scan_full) P.scan_floats = P.ray_floats;
     if (t.width > 8192 || t.height > 8192) { snprintf(g_err, sizeof g_err, "images above 8192 pixels are not supported"); ftgp_destroy(e); return FTGP_ERR_ARG; }
     const int scan_floats = P.ray_floats;
     std::vector<float> ray(2 * (size_t)scan_floats, 0.0f);

@@ -47,7 +47,8 @@ struct DeviceParams {
     int32_t eighth, scan_floats, ray_floats;   // int(n_rays / 8); floats per LDS scan = 1 + (n_rays - 2*eighth) padded to 4; padded ray table
     float snap_eps, pad3;         // the march re-checks a landing point with the exact comparisons within this distance of a pixel boundary
     const uint8_t* field;         // flat per-pixel chessboard distance to the nearest wall pixel (0 = wall, clamp 255), [height][width], HBM/L2
-    int32_t use_field, pad4;      // 1: the march reads `field` (flat, from L2); 0: the two-level grid staged in LDS
+    int32_t use_field;            // 1: the march reads `field` (flat, from L2); 0: the two-level grid staged in LDS
+    int32_t scan_full;            // 1: the LDS scan holds the whole row (flushed to HBM with coalesced 16-B stores); 0: only the driver's window
     const void* veh_dev;          // VehLds image (vehicle constants + wheel loads) in HBM
     const double* path;           // [100][2]
     const double* spawn;          // [100][4] x, y, qw, qz

@@ -304,10 +304,14 @@ __device__ __forceinline__ void lidar_sweep(const DeviceParams& P, const LdsView
                     if (rc < INFINITY && (r < 0.0f || rc < r)) r = rc;
                 }
             }
-            out_g[j] = r;
-            if (out_lds) {      // the on-device driver only reads ranges[0] and ranges[eighth : n - eighth]
-                if (j == 0) out_lds[0] = r;
-                if (j >= P.eighth && j < R - P.eighth) out_lds[1 + j - P.eighth] = r;
+            if (P.scan_full) {
+                out_lds[j] = r;                                   // whole row staged in LDS, flushed below
+            } else {
+                out_g[j] = r;                                     // no LDS room for the row: 4-byte stores, merged in L2
+                if (out_lds) {  // the on-device driver only reads ranges[0] and ranges[eighth : n - eighth]
+                    if (j == 0) out_lds[0] = r;
+                    if (j >= P.eighth && j < R - P.eighth) out_lds[1 + j - P.eighth] = r;
+                }
             }
             j = -1;
         }
@@ -352,6 +356,17 @@ __device__ __forceinline__ void lidar_sweep(const DeviceParams& P, const LdsView
             ray_commit(P, ray, t, cur, stepx, xhi, yhi);
             if (__popcll(__ballot(!ray.active)) >= want_free) break;
         }
+    }
+    if (P.scan_full) {
+        // the row goes to HBM as aligned 16-B-per-lane stores (rows start on 256-B boundaries)
+        wave_lds_sync();
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(1))) f32x4* global_f32x4;
+        const global_f32x4 dst4 = (global_f32x4)out_global;
+        const f32x4* src4 = reinterpret_cast<const f32x4*>(out_lds);
+        const int n4 = R >> 2;
+        for (int i = lane; i < n4; i += FTGP_WAVE) dst4[i] = src4[i];
+        for (int i = (n4 << 2) + lane; i < R; i += FTGP_WAVE) out_g[i] = out_lds[i];
     }
 }
 
@@ -620,7 +635,7 @@ __device__ __attribute__((noinline)) void policy_disparity(const DeviceParams& P
     const double rpp = (2 * M_PI) / (double)n;                      // nidc.py:121
     const int eighth = (int)((double)n / 8.0);                      // nidc.py:18
     const int m = n - 2 * eighth;
-    float* __restrict__ proc = scan + 1;                            // nidc.py:19: ranges[eighth:-eighth] (the copy is the LDS image)
+    float* __restrict__ proc = scan + (P.scan_full ? eighth : 1);    // nidc.py:19: ranges[eighth:-eighth] (the copy is the LDS image)
     const float range0 = scan[0];                                   // ranges[0], fast.py:135
     const double width = (car_width / 2) * (1 + 300.0 / 100);       // nidc.py:93
     // disparities on the UNMODIFIED scan (nidc.py:26-40): one ballot per 64 elements, parked in lane (pass)
@@ -750,8 +765,14 @@ __device__ __forceinline__ LdsView stage_track(const DeviceParams& P, unsigned c
 //   driver(previous scan) -> ctrl -> [mj_step: sensors at the current pose, integrate] -> steps += 1 ->
 //   progress at the new pose (= the head of the next loop iteration).
 // =============================================================================================
+#ifndef FTGP_MAX_THREADS
+#define FTGP_MAX_THREADS 1024     // 16 waves per workgroup -> at most 128 VGPRs per lane
+#endif
+#ifndef FTGP_MIN_WAVES
+#define FTGP_MIN_WAVES 1
+#endif
 template <bool MULTI, bool GF>
-__global__ void __launch_bounds__(1024) ftgp_step_kernel(const DeviceParams* __restrict__ Pg, int policy, int n_steps, int cars_per_block)
+__global__ void __launch_bounds__(FTGP_MAX_THREADS, FTGP_MIN_WAVES) ftgp_step_kernel(const DeviceParams* __restrict__ Pg, int policy, int n_steps, int cars_per_block)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const DeviceParams& P = *reinterpret_cast<const DeviceParams*>(lds + Pg->off_params);   // valid after stage_track + barrier
@@ -768,7 +789,7 @@ __global__ void __launch_bounds__(1024) ftgp_step_kernel(const DeviceParams* __r
     CarCore* states = reinterpret_cast<CarCore*>(lds + P.off_state);
     CarCore* st = states + wave;
     const CarCore* env_cars = states + (wave - my_slot);
-    float* scan = need_scan ? reinterpret_cast<float*>(lds + P.off_scan) + wave * scan_floats : nullptr;
+    float* scan = (need_scan || P.scan_full) ? reinterpret_cast<float*>(lds + P.off_scan) + wave * scan_floats : nullptr;
 
     int64_t steps = 0;
     float* my_ranges = nullptr;
@@ -778,8 +799,12 @@ __global__ void __launch_bounds__(1024) ftgp_step_kernel(const DeviceParams* __r
         steps = P.steps[env];
         my_ranges = P.ranges + (size_t)ci * P.ranges_stride;
         if (need_scan) {
-            if (lane == 0) scan[0] = my_ranges[0];
-            for (int j = P.eighth + lane; j < P.n_rays - P.eighth; j += FTGP_WAVE) scan[1 + j - P.eighth] = my_ranges[j];
+            if (P.scan_full) {
+                for (int j = lane; j < P.n_rays; j += FTGP_WAVE) scan[j] = my_ranges[j];
+            } else {
+                if (lane == 0) scan[0] = my_ranges[0];
+                for (int j = P.eighth + lane; j < P.n_rays - P.eighth; j += FTGP_WAVE) scan[1 + j - P.eighth] = my_ranges[j];
+            }
         }
     }
     __syncthreads();
@@ -835,8 +860,12 @@ __global__ void __launch_bounds__(256) ftgp_policy_kernel(DeviceParams P, int po
     CarCore* st = reinterpret_cast<CarCore*>(lds) + wave;
     float* scan = reinterpret_cast<float*>(lds + 4 * sizeof(CarCore)) + wave * scan_floats;
     const float* my_ranges = P.ranges + (size_t)ci * P.ranges_stride;
-    if (lane == 0) scan[0] = my_ranges[0];
-    for (int j = P.eighth + lane; j < P.n_rays - P.eighth; j += FTGP_WAVE) scan[1 + j - P.eighth] = my_ranges[j];
+    if (P.scan_full) {
+        for (int j = lane; j < P.n_rays; j += FTGP_WAVE) scan[j] = my_ranges[j];
+    } else {
+        if (lane == 0) scan[0] = my_ranges[0];
+        for (int j = P.eighth + lane; j < P.n_rays - P.eighth; j += FTGP_WAVE) scan[1 + j - P.eighth] = my_ranges[j];
+    }
     if (lane < (int)(sizeof(CarCore) / 4))
         reinterpret_cast<uint32_t*>(st)[lane] = reinterpret_cast<const uint32_t*>(static_cast<const CarCore*>(&P.cars[ci]))[lane];
     wave_lds_sync();
