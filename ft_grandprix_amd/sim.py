@@ -164,9 +164,7 @@ class Simulator:
 
     def snapshots(self) -> List[VehicleStateSnapshot]:
         snap = self.env.snapshot()
-        return [VehicleStateSnapshot(laps=int(s[0]), velocity=s[1:4].copy(), yaw=float(s[4]), pitch=float(s[5]),
-                                     roll=float(s[6]), lap_completion=int(s[7]), absolute_completion=int(s[8]),
-                                     time=float(s[9])) for s in snap]
+        return [VehicleStateSnapshot.from_row(row) for row in snap]
 
     def step(self):
         """One iteration of the reference's physics loop body (custom.py:1337-1426)."""
