@@ -71,7 +71,7 @@ struct FtgpEnv {
     hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_metrics = nullptr;
     bool timed = false;
     // device buffers
-    uint8_t* d_coarse = nullptr; uint2* d_rank = nullptr; uint8_t* d_fine = nullptr; uint8_t* d_field = nullptr;
+    uint8_t* d_coarse = nullptr; uint2* d_rank = nullptr; uint8_t* d_fine = nullptr; uint32_t* d_field = nullptr;
     double* d_path = nullptr; double* d_spawn = nullptr; float* d_ray = nullptr; void* d_veh = nullptr; DeviceParams* d_params = nullptr;
     CarState* d_cars = nullptr; float* d_ranges = nullptr; int64_t* d_steps = nullptr;
     uint8_t* d_env_mask = nullptr; uint8_t* d_car_mask = nullptr; double* d_ctrl = nullptr; double* d_pose = nullptr;
@@ -114,7 +114,7 @@ void chessboard_dt(const std::vector<uint8_t>& occ, int W, int H, std::vector<in
 //   rank   : per 32 blocks {non-empty bits, number of non-empty blocks before the word} -> index into fine
 //   coarse : one nibble per block = chessboard distance in blocks to the nearest non-empty block, clamped to 15
 struct HostGrid {
-    std::vector<uint8_t> field;       // flat per-pixel distance, clamp 255
+    std::vector<uint32_t> field;      // flat per-pixel quadrant field (4 x u8)
     int nbx = 0, nby = 0, nwpr = 0, n_fine = 0;
     std::vector<uint8_t> coarse;
     std::vector<uint2> rank;
@@ -134,8 +134,29 @@ void build_grid(const FtgpTrack& t, HostGrid& g)
     std::vector<int> dpx, dblk;
     chessboard_dt(wall, W, H, dpx);
     chessboard_dt(nonempty, g.nbx, g.nby, dblk);
-    g.field.resize((size_t)W * H);
-    for (size_t i = 0; i < g.field.size(); ++i) g.field[i] = (uint8_t)std::min(255, dpx[i]);
+    // quadrant field: byte q of pixel (x, y) = side of the largest wall-free square of pixels with its corner at (x, y)
+    // extending towards (q&1 ? -x : +x, q&2 ? -y : +y); pixels beyond the image count as free; 0 on walls; clamp 255.
+    // Classic largest-square recurrence, one sweep per quadrant.
+    g.field.assign((size_t)W * H, 0u);
+    {
+        std::vector<int> prev((size_t)W + 2), cur((size_t)W + 2);
+        for (int q = 0; q < 4; ++q) {
+            const int sx = (q & 1) ? -1 : 1, sy = (q & 2) ? -1 : 1;
+            std::fill(prev.begin(), prev.end(), 1 << 20);
+            for (int yy = 0; yy < H; ++yy) {
+                const int y = sy > 0 ? H - 1 - yy : yy;          // start at the far edge of the direction of travel
+                std::fill(cur.begin(), cur.end(), 1 << 20);
+                for (int xx = 0; xx < W; ++xx) {
+                    const int x = sx > 0 ? W - 1 - xx : xx;
+                    int v = 0;
+                    if (!wall[(size_t)y * W + x]) v = 1 + std::min(std::min(cur[(size_t)(x + sx + 1)], prev[(size_t)(x + 1)]), prev[(size_t)(x + sx + 1)]);
+                    cur[(size_t)(x + 1)] = v;
+                    g.field[(size_t)y * W + x] |= (uint32_t)std::min(255, v) << (8 * q);
+                }
+                std::swap(prev, cur);
+            }
+        }
+    }
     g.rank.assign((size_t)g.nby * g.nwpr, make_uint2(0u, 0u));
     g.fine.clear(); g.n_fine = 0;
     for (int by = 0; by < g.nby; ++by)
@@ -392,8 +413,8 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
     const size_t sz_fine = (size_t)std::max(16, pad16((size_t)P.n_fine * 32)), sz_rank = (size_t)pad16((size_t)P.nby * P.nwpr * 8);
     const size_t sz_path = (size_t)pad16(sizeof(double) * 2 * FTGP_PATH_POINTS), sz_coarse = (size_t)pad16(((size_t)P.nbx * P.nby + 1) / 2);
     const size_t sz_ray = (size_t)(P.off_state - P.off_ray);
-    CREATE_TRY(hipMalloc(&e->d_field, grid.field.size()));
-    CREATE_TRY(hipMemcpy(e->d_field, grid.field.data(), grid.field.size(), hipMemcpyHostToDevice));
+    CREATE_TRY(hipMalloc(&e->d_field, grid.field.size() * sizeof(uint32_t)));
+    CREATE_TRY(hipMemcpy(e->d_field, grid.field.data(), grid.field.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     P.field = e->d_field;
     {
         std::vector<unsigned char> vimg((size_t)pad16(sizeof(VehLds)), 0);

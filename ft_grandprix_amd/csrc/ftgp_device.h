@@ -46,7 +46,8 @@ struct DeviceParams {
     int32_t off_params, off_veh, off_fine, off_rank, off_path, off_coarse, off_ray, off_state, off_next, off_scan, lds_bytes, pad5;
     int32_t eighth, scan_floats, ray_floats;   // int(n_rays / 8); floats per LDS scan = 1 + (n_rays - 2*eighth) padded to 4; padded ray table
     float snap_eps, pad3;         // the march re-checks a landing point with the exact comparisons within this distance of a pixel boundary
-    const uint8_t* field;         // flat per-pixel chessboard distance to the nearest wall pixel (0 = wall, clamp 255), [height][width], HBM/L2
+    const uint32_t* field;        // flat per-pixel QUADRANT field, [height][width], HBM/L2: byte q = side of the largest wall-free square
+                                  // of pixels with its corner at the pixel, extending towards (q&1 ? -x : +x, q&2 ? -y : +y); 0 = wall, clamp 255
     int32_t use_field;            // 1: the march reads `field` (flat, from L2); 0: the two-level grid staged in LDS
     int32_t scan_full;            // 1: the LDS scan holds the whole row (flushed to HBM with coalesced 16-B stores); 0: only the driver's window
     const void* veh_dev;          // VehLds image (vehicle constants + wheel loads) in HBM

@@ -59,12 +59,16 @@ __host__ __device__ __forceinline__ bool grid_wall(const DeviceParams& P, const 
 }
 
 template <> __device__ __forceinline__ bool wall_px<false>(const DeviceParams& P, const LdsView& L, int cx, int cy) { return grid_wall(P, L, cx, cy); }
-template <> __device__ __forceinline__ bool wall_px<true>(const DeviceParams& P, const LdsView& L, int cx, int cy) { return P.field[cy * P.width + cx] == 0; }
+template <> __device__ __forceinline__ bool wall_px<true>(const DeviceParams& P, const LdsView& L, int cx, int cy) { return (P.field[cy * P.width + cx] & 255u) == 0; }
 // no wall pixel within `reach` pixels (chessboard) of pixel (ix, iy)?
 template <bool GF>
 __device__ __forceinline__ bool far_from_walls(const DeviceParams& P, const LdsView& L, int ix, int iy, int reach)
 {
-    if (GF) return (int)P.field[iy * P.width + ix] > reach;
+    if (GF) {   // the four forward squares of side k cover the (2k-1)^2 pixels around the cell
+        const uint32_t q = P.field[iy * P.width + ix];
+        const uint32_t m = min(min(q & 255u, (q >> 8) & 255u), min((q >> 16) & 255u, q >> 24));
+        return (int)m > reach;
+    }
     return coarse_at(P, L, ix >> 3, iy >> 3) >= ((reach + 7) >> 3) + 1;
 }
 
@@ -90,6 +94,7 @@ struct Ray {
     float pum, pvm, dum, dvm, ivx, ivy;   // mirrored origin / direction / inverse direction (0 where the direction is 0)
     float s, result;
     int ix, iy, mx, my;                   // mirrored cell; mirror masks (0 or -1)
+    int qshift;                           // bit offset of this ray's direction quadrant in a quadrant-field word
     bool active;
 };
 
@@ -97,6 +102,7 @@ __host__ __device__ __forceinline__ void ray_init(const DeviceParams& P, Ray& r,
 {
     const int ix0 = (int)floorf(pu), iy0 = (int)floorf(pv);
     r.mx = du < 0.0f ? -1 : 0; r.my = dv < 0.0f ? -1 : 0;
+    r.qshift = ((r.mx & 1) | ((r.my & 1) << 1)) << 3;
     r.pum = r.mx ? -pu : pu; r.pvm = r.my ? -pv : pv;
     r.dum = fabsf(du); r.dvm = fabsf(dv);
     r.ivx = (du != 0.0f) ? fabsf(1.0f / du) : 0.0f;
@@ -273,13 +279,13 @@ __device__ __forceinline__ void lidar_sweep(const DeviceParams& P, const LdsView
     const unsigned char* lds_base = reinterpret_cast<const unsigned char*>(L.veh) - P.off_veh;
     const uint2* rank = L.rank;
     // the pointers come out of the LDS parameter block: tell the compiler they are global (global_load / global_store, not flat)
-    typedef const __attribute__((address_space(1))) uint8_t* global_u8;
+    typedef const __attribute__((address_space(1))) uint32_t* global_u32;
     typedef __attribute__((address_space(1))) float* global_f32;
-    const global_u8 field = (global_u8)P.field;
+    const global_u32 field = (global_u32)P.field;
     const global_f32 out_g = (global_f32)out_global;
     const int W = P.width;
 
-    Ray ray; ray.active = false; ray.result = -1.0f; ray.s = 0.0f;
+    Ray ray; ray.active = false; ray.result = -1.0f; ray.s = 0.0f; ray.qshift = 0;
     ray.pum = ray.pvm = ray.dum = ray.dvm = ray.ivx = ray.ivy = 0.0f; ray.ix = ray.iy = ray.mx = ray.my = 0;
     float dxw = 0.0f, dyw = 0.0f;
     int j = -1;              // the ray this lane is marching (or has just finished); -1: none
@@ -341,9 +347,10 @@ __device__ __forceinline__ void lidar_sweep(const DeviceParams& P, const LdsView
         for (int guard = 0; guard < 8192; ++guard) {
             Probe pb; unsigned b2;
             if (GF) {
-                // flat per-pixel field from L2: one byte, no indirection (pixel-distance semantics for every cell)
+                // flat quadrant field from L2: one dword per pixel, no indirection; the byte of the ray's own quadrant is the
+                // side of the wall-free square AHEAD of the cell (walls beside or behind the ray do not shorten the jump)
                 const int tx = ray.ix ^ ray.mx, ty = ray.iy ^ ray.my;
-                pb.nonempty = true; pb.shift2 = 0; pb.addr2 = 0;
+                pb.nonempty = true; pb.shift2 = ray.qshift; pb.addr2 = 0;
                 b2 = field[ty * W + tx];
             } else {
                 const uint2 rk = rank[ray_rank_addr(P, ray)];
