@@ -114,7 +114,8 @@ void chessboard_dt(const std::vector<uint8_t>& occ, int W, int H, std::vector<in
 //   rank   : per 32 blocks {non-empty bits, number of non-empty blocks before the word} -> index into fine
 //   coarse : one nibble per block = chessboard distance in blocks to the nearest non-empty block, clamped to 15
 struct HostGrid {
-    std::vector<uint32_t> field;      // flat per-pixel quadrant field (4 x u8)
+    std::vector<uint8_t> ksq;         // [4][H][W] largest wall-free forward square per quadrant (clamp 255)
+    std::vector<uint16_t> runx, runy; // [2][H][W] wall-free run lengths along +x / -x and +y / -y (65535 = beyond the image)
     int nbx = 0, nby = 0, nwpr = 0, n_fine = 0;
     std::vector<uint8_t> coarse;
     std::vector<uint2> rank;
@@ -134,10 +135,11 @@ void build_grid(const FtgpTrack& t, HostGrid& g)
     std::vector<int> dpx, dblk;
     chessboard_dt(wall, W, H, dpx);
     chessboard_dt(nonempty, g.nbx, g.nby, dblk);
-    // quadrant field: byte q of pixel (x, y) = side of the largest wall-free square of pixels with its corner at (x, y)
-    // extending towards (q&1 ? -x : +x, q&2 ? -y : +y); pixels beyond the image count as free; 0 on walls; clamp 255.
-    // Classic largest-square recurrence, one sweep per quadrant.
-    g.field.assign((size_t)W * H, 0u);
+    // inputs of the octant field (the rectangles themselves are searched on the GPU, ftgp_octant_field_kernel):
+    //   ksq[q](x, y) = side of the largest wall-free square of pixels with its corner at (x, y), extending towards
+    //   (q&1 ? -x : +x, q&2 ? -y : +y); pixels beyond the image count as free; 0 on walls.  Classic largest-square recurrence.
+    const size_t plane = (size_t)W * H;
+    g.ksq.assign(4 * plane, 0);
     {
         std::vector<int> prev((size_t)W + 2), cur((size_t)W + 2);
         for (int q = 0; q < 4; ++q) {
@@ -151,11 +153,24 @@ void build_grid(const FtgpTrack& t, HostGrid& g)
                     int v = 0;
                     if (!wall[(size_t)y * W + x]) v = 1 + std::min(std::min(cur[(size_t)(x + sx + 1)], prev[(size_t)(x + 1)]), prev[(size_t)(x + sx + 1)]);
                     cur[(size_t)(x + 1)] = v;
-                    g.field[(size_t)y * W + x] |= (uint32_t)std::min(255, v) << (8 * q);
+                    g.ksq[(size_t)q * plane + (size_t)y * W + x] = (uint8_t)std::min(255, v);
                 }
                 std::swap(prev, cur);
             }
         }
+    }
+    g.runx.assign(2 * plane, 0); g.runy.assign(2 * plane, 0);
+    for (int y = 0; y < H; ++y) {
+        int r = 65535;
+        for (int x = W - 1; x >= 0; --x) { r = wall[(size_t)y * W + x] ? 0 : std::min(65535, r + 1); g.runx[(size_t)y * W + x] = (uint16_t)r; }
+        r = 65535;
+        for (int x = 0; x < W; ++x) { r = wall[(size_t)y * W + x] ? 0 : std::min(65535, r + 1); g.runx[plane + (size_t)y * W + x] = (uint16_t)r; }
+    }
+    for (int x = 0; x < W; ++x) {
+        int r = 65535;
+        for (int y = H - 1; y >= 0; --y) { r = wall[(size_t)y * W + x] ? 0 : std::min(65535, r + 1); g.runy[(size_t)y * W + x] = (uint16_t)r; }
+        r = 65535;
+        for (int y = 0; y < H; ++y) { r = wall[(size_t)y * W + x] ? 0 : std::min(65535, r + 1); g.runy[plane + (size_t)y * W + x] = (uint16_t)r; }
     }
     g.rank.assign((size_t)g.nby * g.nwpr, make_uint2(0u, 0u));
     g.fine.clear(); g.n_fine = 0;
@@ -413,9 +428,22 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
     const size_t sz_fine = (size_t)std::max(16, pad16((size_t)P.n_fine * 32)), sz_rank = (size_t)pad16((size_t)P.nby * P.nwpr * 8);
     const size_t sz_path = (size_t)pad16(sizeof(double) * 2 * FTGP_PATH_POINTS), sz_coarse = (size_t)pad16(((size_t)P.nbx * P.nby + 1) / 2);
     const size_t sz_ray = (size_t)(P.off_state - P.off_ray);
-    CREATE_TRY(hipMalloc(&e->d_field, grid.field.size() * sizeof(uint32_t)));
-    CREATE_TRY(hipMemcpy(e->d_field, grid.field.data(), grid.field.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    P.field = e->d_field;
+    {   // octant field: upload the squares and run lengths, search the rectangles on the device
+        const size_t plane = (size_t)t.width * t.height;
+        uint8_t* d_ksq = nullptr; uint16_t* d_runx = nullptr; uint16_t* d_runy = nullptr;
+        CREATE_TRY(hipMalloc(&e->d_field, 2 * plane * sizeof(uint32_t)));
+        CREATE_TRY(hipMalloc(&d_ksq, 4 * plane));
+        CREATE_TRY(hipMalloc(&d_runx, 2 * plane * sizeof(uint16_t)));
+        CREATE_TRY(hipMalloc(&d_runy, 2 * plane * sizeof(uint16_t)));
+        CREATE_TRY(hipMemcpy(d_ksq, grid.ksq.data(), 4 * plane, hipMemcpyHostToDevice));
+        CREATE_TRY(hipMemcpy(d_runx, grid.runx.data(), 2 * plane * sizeof(uint16_t), hipMemcpyHostToDevice));
+        CREATE_TRY(hipMemcpy(d_runy, grid.runy.data(), 2 * plane * sizeof(uint16_t), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(ftgp_octant_field_kernel, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, e->stream, d_ksq, d_runx, d_runy, t.width, t.height, e->d_field);
+        CREATE_TRY(hipGetLastError());
+        CREATE_TRY(hipStreamSynchronize(e->stream));
+        (void)hipFree(d_ksq); (void)hipFree(d_runx); (void)hipFree(d_runy);
+        P.field = e->d_field;
+    }
     {
         std::vector<unsigned char> vimg((size_t)pad16(sizeof(VehLds)), 0);
         VehLds vl; vl.v = P.veh; for (int i = 0; i < 4; ++i) vl.wheel_load[i] = P.wheel_load[i];

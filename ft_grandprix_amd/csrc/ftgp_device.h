@@ -46,8 +46,11 @@ struct DeviceParams {
     int32_t off_params, off_veh, off_fine, off_rank, off_path, off_coarse, off_ray, off_state, off_next, off_scan, lds_bytes, pad5;
     int32_t eighth, scan_floats, ray_floats;   // int(n_rays / 8); floats per LDS scan = 1 + (n_rays - 2*eighth) padded to 4; padded ray table
     float snap_eps, pad3;         // the march re-checks a landing point with the exact comparisons within this distance of a pixel boundary
-    const uint32_t* field;        // flat per-pixel QUADRANT field, [height][width], HBM/L2: byte q = side of the largest wall-free square
-                                  // of pixels with its corner at the pixel, extending towards (q&1 ? -x : +x, q&2 ? -y : +y); 0 = wall, clamp 255
+    const uint32_t* field;        // flat per-pixel OCTANT field, [height][width][2] dwords, HBM/L2.  Dword 0 serves rays whose dominant
+                                  // axis is x, dword 1 those with dominant axis y; byte q of a dword belongs to the direction quadrant
+                                  // (q&1 ? -x : +x, q&2 ? -y : +y).  A byte describes a wall-free rectangle of pixels with its corner
+                                  // at the pixel, extending AHEAD of the ray: low 7 bits = h (0 = the pixel is a wall); bit 7 clear:
+                                  // h x h square; bit 7 set: 2h along the dominant axis by h across it.
     int32_t use_field;            // 1: the march reads `field` (flat, from L2); 0: the two-level grid staged in LDS
     int32_t scan_full;            // 1: the LDS scan holds the whole row (flushed to HBM with coalesced 16-B stores); 0: only the driver's window
     const void* veh_dev;          // VehLds image (vehicle constants + wheel loads) in HBM

@@ -7,7 +7,8 @@
 //       range stores, the only per-step HBM traffic besides scratch); contact candidates and the centre-line argmin are
 //       spread over lanes and resolved with wave-level min/max reductions; the driver's disparity masks come from wave
 //       ballots.  The march skips wall-free cells with one of two interchangeable structures (template flag GF):
-//         GF = true  : flat per-pixel chessboard distance field, one byte per pixel, read from L2 (default)
+//         GF = true  : flat per-pixel octant field read from L2 (default): per direction octant the wall-free square or 2:1
+//                      rectangle of pixels AHEAD of the cell -- walls beside or behind a ray never shorten its jumps
 //         GF = false : two-level grid over 8x8-pixel blocks staged in LDS (4-bit block distances, 4-bit pixel distances
 //                      of non-empty blocks behind a rank table)
 //       Both return the bits of the plain-DDA specification.
@@ -59,14 +60,14 @@ __host__ __device__ __forceinline__ bool grid_wall(const DeviceParams& P, const 
 }
 
 template <> __device__ __forceinline__ bool wall_px<false>(const DeviceParams& P, const LdsView& L, int cx, int cy) { return grid_wall(P, L, cx, cy); }
-template <> __device__ __forceinline__ bool wall_px<true>(const DeviceParams& P, const LdsView& L, int cx, int cy) { return (P.field[cy * P.width + cx] & 255u) == 0; }
+template <> __device__ __forceinline__ bool wall_px<true>(const DeviceParams& P, const LdsView& L, int cx, int cy) { return (P.field[2 * (cy * P.width + cx)] & 127u) == 0; }
 // no wall pixel within `reach` pixels (chessboard) of pixel (ix, iy)?
 template <bool GF>
 __device__ __forceinline__ bool far_from_walls(const DeviceParams& P, const LdsView& L, int ix, int iy, int reach)
 {
-    if (GF) {   // the four forward squares of side k cover the (2k-1)^2 pixels around the cell
-        const uint32_t q = P.field[iy * P.width + ix];
-        const uint32_t m = min(min(q & 255u, (q >> 8) & 255u), min((q >> 16) & 255u, q >> 24));
+    if (GF) {   // every stored rectangle contains the h x h forward square; four such squares cover the (2h-1)^2 pixels around the cell
+        const uint32_t q = P.field[2 * (iy * P.width + ix)];
+        const uint32_t m = min(min(q & 127u, (q >> 8) & 127u), min((q >> 16) & 127u, (q >> 24) & 127u));
         return (int)m > reach;
     }
     return coarse_at(P, L, ix >> 3, iy >> 3) >= ((reach + 7) >> 3) + 1;
@@ -94,7 +95,8 @@ struct Ray {
     float pum, pvm, dum, dvm, ivx, ivy;   // mirrored origin / direction / inverse direction (0 where the direction is 0)
     float s, result;
     int ix, iy, mx, my;                   // mirrored cell; mirror masks (0 or -1)
-    int qshift;                           // bit offset of this ray's direction quadrant in a quadrant-field word
+    int qshift;                           // bit offset of this ray's direction quadrant in an octant-field dword
+    int dom;                              // 0: |du| >= |dv| (x-dominant), 1: y-dominant
     bool active;
 };
 
@@ -103,6 +105,7 @@ __host__ __device__ __forceinline__ void ray_init(const DeviceParams& P, Ray& r,
     const int ix0 = (int)floorf(pu), iy0 = (int)floorf(pv);
     r.mx = du < 0.0f ? -1 : 0; r.my = dv < 0.0f ? -1 : 0;
     r.qshift = ((r.mx & 1) | ((r.my & 1) << 1)) << 3;
+    r.dom = fabsf(du) >= fabsf(dv) ? 0 : 1;
     r.pum = r.mx ? -pu : pu; r.pvm = r.my ? -pv : pv;
     r.dum = fabsf(du); r.dvm = fabsf(dv);
     r.ivx = (du != 0.0f) ? fabsf(1.0f / du) : 0.0f;
@@ -117,6 +120,8 @@ __host__ __device__ __forceinline__ void ray_init(const DeviceParams& P, Ray& r,
 //   stage 1: the rank word of the ray's block (non-empty bit + running count)            -> 1 LDS read
 //   stage 2: EITHER the block-distance nibble (empty block) OR the pixel-distance nibble  -> 1 LDS read
 struct Probe { int addr2, shift2; bool nonempty; };
+// wall-free rectangle ahead of the cell, in cells: [ix, ix + kx) x [iy, iy + ky) in the mirrored frame; hit: the cell is a wall
+struct Ahead { int kx, ky; bool hit; };
 
 __host__ __device__ __forceinline__ int ray_rank_addr(const DeviceParams& P, const Ray& r)
 {
@@ -138,16 +143,38 @@ __host__ __device__ __forceinline__ Probe ray_probe(const DeviceParams& P, const
     return p;
 }
 
+// decode of the two-level grid lookup (nibble = pixel distance in a non-empty block, block distance in an empty one)
+__host__ __device__ __forceinline__ Ahead ahead_from_grid(const Ray& r, const Probe& pb, unsigned byte2)
+{
+    const int k = (int)(byte2 >> pb.shift2) & 15;
+    Ahead a;
+    a.hit = pb.nonempty & (k == 0);
+    a.kx = pb.nonempty ? k : ((((r.ix >> 3) + k) << 3) - r.ix);
+    a.ky = pb.nonempty ? k : ((((r.iy >> 3) + k) << 3) - r.iy);
+    return a;
+}
+// decode of one octant-field byte
+__host__ __device__ __forceinline__ Ahead ahead_from_octant(const Ray& r, unsigned dword)
+{
+    const unsigned b = (dword >> r.qshift) & 255u;
+    const int h = (int)(b & 127u);
+    const int wide = (int)(b >> 7);                      // 1: 2h along the dominant axis
+    Ahead a;
+    a.hit = h == 0;
+    a.kx = h << (wide & (r.dom ^ 1));
+    a.ky = h << (wide & r.dom);
+    return a;
+}
+
 // returns true when the landing point was too close to a pixel boundary to trust floor(): the caller then runs ray_fix()
-__host__ __device__ __forceinline__ bool ray_step(const DeviceParams& P, Ray& r, const Probe& pb, unsigned byte2, int kmask,
+__host__ __device__ __forceinline__ bool ray_step(const DeviceParams& P, Ray& r, const Ahead& ah,
                                                   int& t_out, int& cur_out, int& hi_out, bool& stepx_out, int& xhi_out, int& yhi_out)
 {
-    const int k = (int)(byte2 >> pb.shift2) & kmask;               // pixel distance (non-empty block / flat field) or block distance (empty block)
-    const bool hit = r.active & pb.nonempty & (k == 0);
+    const bool hit = r.active & ah.hit;
     r.result = hit ? fabsf(r.s) : r.result;
     r.active = r.active & !hit;
-    const int xhi = pb.nonempty ? r.ix + k - 1 : (((r.ix >> 3) + k) << 3) - 1;
-    const int yhi = pb.nonempty ? r.iy + k - 1 : (((r.iy >> 3) + k) << 3) - 1;
+    const int xhi = r.ix + ah.kx - 1;
+    const int yhi = r.iy + ah.ky - 1;
     const float sX = (r.dum != 0.0f) ? ((float)(xhi + 1) - r.pum) * r.ivx : INFINITY;
     const float sY = (r.dvm != 0.0f) ? ((float)(yhi + 1) - r.pvm) * r.ivy : INFINITY;
     const bool stepx = sX < sY;
@@ -196,7 +223,7 @@ __host__ __device__ __forceinline__ float march_grid(const DeviceParams& P, cons
         const uint2 rk = rank[ray_rank_addr(P, r)];
         const Probe pb = ray_probe(P, r, rk);
         int t, cur, hi, xhi, yhi; bool stepx;
-        const bool near = ray_step(P, r, pb, lds[pb.addr2], 15, t, cur, hi, stepx, xhi, yhi);
+        const bool near = ray_step(P, r, ahead_from_grid(r, pb, lds[pb.addr2]), t, cur, hi, stepx, xhi, yhi);
         if (near) t = ray_fix(r, t, cur, hi, stepx);
         ray_commit(P, r, t, cur, stepx, xhi, yhi);
     }
@@ -254,10 +281,10 @@ __device__ __forceinline__ float ray_vs_car(const FtgpVehicle& v, const CarCore*
 // one batched ray_init for all of them) while the unfinished rays simply carry on.  On the headline workload this cuts
 // the wave-iterations per car from 245 (sum of per-pass maxima) to ~170 (ideal 135); which lane marches which ray has no
 // influence on any result.
-// measured on MI355X (tools/sweep_refill.sh): 24 free lanes for single-car envs, 48 for multi-car envs (their refill
-// block also runs the inter-vehicle tests); 64 would be the classic "wait for the slowest ray" pass
+// measured on MI355X (tools/sweep_refill.sh): flat optimum around 36-48 free lanes; 40 for single-car envs, 48 for multi-car
+// envs (their refill block also runs the inter-vehicle tests); 64 would be the classic "wait for the slowest ray" pass
 #ifndef FTGP_REFILL
-#define FTGP_REFILL (MULTI ? 48 : 24)
+#define FTGP_REFILL (MULTI ? 48 : 40)
 #endif
 template <bool MULTI, bool GF>
 __device__ __forceinline__ void lidar_sweep(const DeviceParams& P, const LdsView& L, const CarCore* st, float* __restrict__ out_global,
@@ -285,7 +312,7 @@ __device__ __forceinline__ void lidar_sweep(const DeviceParams& P, const LdsView
     const global_f32 out_g = (global_f32)out_global;
     const int W = P.width;
 
-    Ray ray; ray.active = false; ray.result = -1.0f; ray.s = 0.0f; ray.qshift = 0;
+    Ray ray; ray.active = false; ray.result = -1.0f; ray.s = 0.0f; ray.qshift = 0; ray.dom = 0;
     ray.pum = ray.pvm = ray.dum = ray.dvm = ray.ivx = ray.ivy = 0.0f; ray.ix = ray.iy = ray.mx = ray.my = 0;
     float dxw = 0.0f, dyw = 0.0f;
     int j = -1;              // the ray this lane is marching (or has just finished); -1: none
@@ -345,20 +372,19 @@ __device__ __forceinline__ void lidar_sweep(const DeviceParams& P, const LdsView
         // ---- march until enough lanes are free to make a batched refill worthwhile (or, at the end, until all are done)
         const int want_free = (next < R) ? FTGP_REFILL : FTGP_WAVE;
         for (int guard = 0; guard < 8192; ++guard) {
-            Probe pb; unsigned b2;
+            Ahead ah;
             if (GF) {
-                // flat quadrant field from L2: one dword per pixel, no indirection; the byte of the ray's own quadrant is the
-                // side of the wall-free square AHEAD of the cell (walls beside or behind the ray do not shorten the jump)
+                // flat octant field from L2: one dword per (pixel, dominant axis), no indirection; the byte of the ray's own
+                // quadrant is the wall-free rectangle AHEAD of the cell (walls beside or behind the ray do not shorten the jump)
                 const int tx = ray.ix ^ ray.mx, ty = ray.iy ^ ray.my;
-                pb.nonempty = true; pb.shift2 = ray.qshift; pb.addr2 = 0;
-                b2 = field[ty * W + tx];
+                ah = ahead_from_octant(ray, field[2 * (ty * W + tx) + ray.dom]);
             } else {
                 const uint2 rk = rank[ray_rank_addr(P, ray)];
-                pb = ray_probe(P, ray, rk);
-                b2 = lds_base[pb.addr2];
+                const Probe pb = ray_probe(P, ray, rk);
+                ah = ahead_from_grid(ray, pb, lds_base[pb.addr2]);
             }
             int t, cur, hi, xhi, yhi; bool stepx;
-            const bool near = ray_step(P, ray, pb, b2, GF ? 255 : 15, t, cur, hi, stepx, xhi, yhi);
+            const bool near = ray_step(P, ray, ah, t, cur, hi, stepx, xhi, yhi);
             if (__any(near)) { const int tf = ray_fix(ray, t, cur, hi, stepx); t = near ? tf : t; }
             ray_commit(P, ray, t, cur, stepx, xhi, yhi);
             if (__popcll(__ballot(!ray.active)) >= want_free) break;
@@ -999,6 +1025,43 @@ __global__ void ftgp_fakelidar_kernel(const double* __restrict__ dt, int H, int 
     }
     if (bad) atomicOr(index_error, 1);
     scan[i] = distance; points[2 * i] = x; points[2 * i + 1] = y;
+}
+
+// Octant field build (ftgp_create): one pixel per lane.  ksq[q] = side of the largest wall-free square ahead of the pixel in
+// quadrant q (host recurrence); run*[d] = wall-free run length starting at the pixel along +x, -x, +y, -y (65535 = to the edge
+// and beyond).  For each quadrant and dominant axis the largest h with a wall-free (2h along the axis) x (h across) rectangle is
+// found by walking the h rows (columns) with a running minimum of the run lengths; the rectangle is stored when it reaches
+// farther along the dominant axis than the square.
+__global__ void ftgp_octant_field_kernel(const uint8_t* __restrict__ ksq, const uint16_t* __restrict__ runx, const uint16_t* __restrict__ runy,
+                                         int W, int H, uint32_t* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= W * H) return;
+    const int x = i % W, y = i / W;
+    const size_t plane = (size_t)W * H;
+    uint32_t word[2] = { 0u, 0u };
+    for (int q = 0; q < 4; ++q) {
+        const int k = ksq[(size_t)q * plane + i];
+        if (k == 0) continue;                                     // wall: all bytes stay 0
+        const int sx = (q & 1) ? -1 : 1, sy = (q & 2) ? -1 : 1;
+        const uint16_t* rx = runx + ((q & 1) ? plane : 0);        // runs along the quadrant's x direction
+        const uint16_t* ry = runy + ((q & 2) ? plane : 0);
+        for (int dom = 0; dom < 2; ++dom) {
+            int h = 0, m = 65535;
+            for (; h < 127; ++h) {
+                int r;
+                if (dom == 0) { const int yy = y + sy * h; r = (yy >= 0 && yy < H) ? (int)rx[(size_t)yy * W + x] : 65535; }
+                else          { const int xx = x + sx * h; r = (xx >= 0 && xx < W) ? (int)ry[(size_t)y * W + xx] : 65535; }
+                m = r < m ? r : m;
+                if (m < 2 * (h + 1)) break;
+            }
+            const int ks = k < 127 ? k : 127;
+            const uint32_t byte = (2 * h > ks) ? (0x80u | (uint32_t)h) : (uint32_t)ks;
+            word[dom] |= byte << (8 * q);
+        }
+    }
+    out[2 * (size_t)i] = word[0];
+    out[2 * (size_t)i + 1] = word[1];
 }
 
 // Metrics record (FTGP_METRIC_DOUBLES): one block, deterministic tree reduction (integers are exact in f64).
