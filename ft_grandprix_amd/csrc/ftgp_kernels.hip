@@ -286,6 +286,9 @@ __device__ __forceinline__ float ray_vs_car(const FtgpVehicle& v, const CarCore*
 #ifndef FTGP_REFILL
 #define FTGP_REFILL (MULTI ? 48 : 40)
 #endif
+#ifndef FTGP_SLOTS
+#define FTGP_SLOTS 1
+#endif
 template <bool MULTI, bool GF>
 __device__ __forceinline__ void lidar_sweep(const DeviceParams& P, const LdsView& L, const CarCore* st, float* __restrict__ out_global,
                                             float* __restrict__ out_lds, const CarCore* env_cars, int my_slot)
@@ -312,83 +315,111 @@ __device__ __forceinline__ void lidar_sweep(const DeviceParams& P, const LdsView
     const global_f32 out_g = (global_f32)out_global;
     const int W = P.width;
 
-    Ray ray; ray.active = false; ray.result = -1.0f; ray.s = 0.0f; ray.qshift = 0; ray.dom = 0;
-    ray.pum = ray.pvm = ray.dum = ray.dvm = ray.ivx = ray.ivy = 0.0f; ray.ix = ray.iy = ray.mx = ray.my = 0;
-    float dxw = 0.0f, dyw = 0.0f;
-    int j = -1;              // the ray this lane is marching (or has just finished); -1: none
+    // FTGP_SLOTS independent rays per lane (instruction-level parallelism: that many field loads in flight per wave)
+    Ray ray[FTGP_SLOTS]; float dxw[FTGP_SLOTS], dyw[FTGP_SLOTS]; int j[FTGP_SLOTS];
+    #pragma unroll
+    for (int q = 0; q < FTGP_SLOTS; ++q) {
+        ray[q].active = false; ray[q].result = -1.0f; ray[q].s = 0.0f; ray[q].qshift = 0; ray[q].dom = 0;
+        ray[q].pum = ray[q].pvm = ray[q].dum = ray[q].dvm = ray[q].ivx = ray[q].ivy = 0.0f;
+        ray[q].ix = ray[q].iy = ray[q].mx = ray[q].my = 0;
+        dxw[q] = dyw[q] = 0.0f;
+        j[q] = -1;           // the ray this slot is marching (or has just finished); -1: none
+    }
     int next = 0;            // first ray not handed out yet (wave-uniform)
     for (int round = 0; round < 4 * 8192; ++round) {
-        // ---- lanes whose ray is finished: store its range, then take the next ray in index order
-        const bool idle = !ray.active;
-        if (idle && j >= 0) {
-            float r = ray.result;
-            if (MULTI) {
-                // conservative cull before the exact box / puck tests: every visible part of a car lies within 0.114 of
-                // its origin (chassis corner 0.1137, puck 0.0825), so a car whose origin is farther than 0.125 from the
-                // ray, behind its start, or beyond the wall hit cannot change the range.  Results are unaffected.
-                const float ox = (float)lcx - r0 * dxw, oy = (float)lcy - r0 * dyw;
-                for (int k = 0; k < P.cars_per_env; ++k) {
-                    if (k == my_slot || env_cars[k].finished) continue;      // shadowed cars are invisible (custom.py:1441-1466)
-                    const float wx = (float)env_cars[k].x - ox, wy = (float)env_cars[k].y - oy;
-                    const float along = wx * dxw + wy * dyw;
-                    const float perp2 = (wx * wx + wy * wy) - along * along;
-                    if (perp2 > 0.125f * 0.125f || along < -0.125f || (r >= 0.0f && along - 0.125f > r)) continue;
-                    const float rc = ray_vs_car(v, env_cars + k, lcx, lcy, dxw, dyw);
-                    if (rc < INFINITY && (r < 0.0f || rc < r)) r = rc;
+        // ---- slots whose ray is finished: store its range, then take the next ray in index order
+        int n_idle = 0; bool any_pending = false;
+        #pragma unroll
+        for (int q = 0; q < FTGP_SLOTS; ++q) {
+            const bool idle = !ray[q].active;
+            if (idle && j[q] >= 0) {
+                float r = ray[q].result;
+                if (MULTI) {
+                    // conservative cull before the exact box / puck tests: every visible part of a car lies within 0.114 of
+                    // its origin (chassis corner 0.1137, puck 0.0825), so a car whose origin is farther than 0.125 from the
+                    // ray, behind its start, or beyond the wall hit cannot change the range.  Results are unaffected.
+                    const float ox = (float)lcx - r0 * dxw[q], oy = (float)lcy - r0 * dyw[q];
+                    for (int k = 0; k < P.cars_per_env; ++k) {
+                        if (k == my_slot || env_cars[k].finished) continue;      // shadowed cars are invisible (custom.py:1441-1466)
+                        const float wx = (float)env_cars[k].x - ox, wy = (float)env_cars[k].y - oy;
+                        const float along = wx * dxw[q] + wy * dyw[q];
+                        const float perp2 = (wx * wx + wy * wy) - along * along;
+                        if (perp2 > 0.125f * 0.125f || along < -0.125f || (r >= 0.0f && along - 0.125f > r)) continue;
+                        const float rc = ray_vs_car(v, env_cars + k, lcx, lcy, dxw[q], dyw[q]);
+                        if (rc < INFINITY && (r < 0.0f || rc < r)) r = rc;
+                    }
                 }
-            }
-            if (P.scan_full) {
-                out_lds[j] = r;                                   // whole row staged in LDS, flushed below
-            } else {
-                out_g[j] = r;                                     // no LDS room for the row: 4-byte stores, merged in L2
-                if (out_lds) {  // the on-device driver only reads ranges[0] and ranges[eighth : n - eighth]
-                    if (j == 0) out_lds[0] = r;
-                    if (j >= P.eighth && j < R - P.eighth) out_lds[1 + j - P.eighth] = r;
+                if (P.scan_full) {
+                    out_lds[j[q]] = r;                                // whole row staged in LDS, flushed below
+                } else {
+                    out_g[j[q]] = r;                                  // no LDS room for the row: 4-byte stores, merged in L2
+                    if (out_lds) {  // the on-device driver only reads ranges[0] and ranges[eighth : n - eighth]
+                        if (j[q] == 0) out_lds[0] = r;
+                        if (j[q] >= P.eighth && j[q] < R - P.eighth) out_lds[1 + j[q] - P.eighth] = r;
+                    }
                 }
+                j[q] = -1;
             }
-            j = -1;
-        }
-        const uint64_t idle_mask = __ballot(idle);
-        if (next < R) {
-            const int mine = next + __popcll(idle_mask & lanes_below);
-            if (idle && mine < R) {
-                j = mine;
-                const float bx = L.ray_bx[j], by = L.ray_by[j];
-                dxw = fmaf(chf, bx, -(shf * by));
-                dyw = fmaf(shf, bx, chf * by);
-                const float du = dxw * isx;
-                const float dv = -(dyw * isy);
-                const float pu = fmaf(du, -r0, u0);
-                const float pv = fmaf(dv, -r0, v0);
-                ray_init(P, ray, pu, pv, du, dv, true);
+            const uint64_t idle_mask = __ballot(idle);
+            if (next < R) {
+                const int mine = next + __popcll(idle_mask & lanes_below);
+                if (idle && mine < R) {
+                    j[q] = mine;
+                    const float bx = L.ray_bx[mine], by = L.ray_by[mine];
+                    dxw[q] = fmaf(chf, bx, -(shf * by));
+                    dyw[q] = fmaf(shf, bx, chf * by);
+                    const float du = dxw[q] * isx;
+                    const float dv = -(dyw[q] * isy);
+                    const float pu = fmaf(du, -r0, u0);
+                    const float pv = fmaf(dv, -r0, v0);
+                    ray_init(P, ray[q], pu, pv, du, dv, true);
+                }
+                next += __popcll(idle_mask);
             }
-            next += __popcll(idle_mask);
+            any_pending |= j[q] >= 0;
         }
-        const uint64_t live_mask = __ballot(ray.active);
-        if (live_mask == 0) {
-            if (next >= R && !__any(j >= 0)) break;      // nothing marching, nothing to store, nothing left to hand out
-            continue;                                    // e.g. rays that started outside the image: store them and refill
+        bool any_active = false;
+        #pragma unroll
+        for (int q = 0; q < FTGP_SLOTS; ++q) any_active |= ray[q].active;
+        if (!__any(any_active)) {
+            if (next >= R && !__any(any_pending)) break;     // nothing marching, nothing to store, nothing left to hand out
+            continue;                                        // e.g. rays that started outside the image: store them and refill
         }
-        // ---- march until enough lanes are free to make a batched refill worthwhile (or, at the end, until all are done)
-        const int want_free = (next < R) ? FTGP_REFILL : FTGP_WAVE;
+        // ---- march until enough slots are free to make a batched refill worthwhile (or, at the end, until all are done)
+        const int want_free = (next < R) ? FTGP_REFILL * FTGP_SLOTS : FTGP_WAVE * FTGP_SLOTS;
         for (int guard = 0; guard < 8192; ++guard) {
-            Ahead ah;
+            Ahead ah[FTGP_SLOTS];
             if (GF) {
                 // flat octant field from L2: one dword per (pixel, dominant axis), no indirection; the byte of the ray's own
                 // quadrant is the wall-free rectangle AHEAD of the cell (walls beside or behind the ray do not shorten the jump)
-                const int tx = ray.ix ^ ray.mx, ty = ray.iy ^ ray.my;
-                ah = ahead_from_octant(ray, field[2 * (ty * W + tx) + ray.dom]);
+                unsigned w[FTGP_SLOTS];
+                #pragma unroll
+                for (int q = 0; q < FTGP_SLOTS; ++q) {
+                    const int tx = ray[q].ix ^ ray[q].mx, ty = ray[q].iy ^ ray[q].my;
+                    w[q] = field[2 * (ty * W + tx) + ray[q].dom];
+                }
+                #pragma unroll
+                for (int q = 0; q < FTGP_SLOTS; ++q) ah[q] = ahead_from_octant(ray[q], w[q]);
             } else {
-                const uint2 rk = rank[ray_rank_addr(P, ray)];
-                const Probe pb = ray_probe(P, ray, rk);
-                ah = ahead_from_grid(ray, pb, lds_base[pb.addr2]);
+                #pragma unroll
+                for (int q = 0; q < FTGP_SLOTS; ++q) {
+                    const uint2 rk = rank[ray_rank_addr(P, ray[q])];
+                    const Probe pb = ray_probe(P, ray[q], rk);
+                    ah[q] = ahead_from_grid(ray[q], pb, lds_base[pb.addr2]);
+                }
             }
-            int t, cur, hi, xhi, yhi; bool stepx;
-            const bool near = ray_step(P, ray, ah, t, cur, hi, stepx, xhi, yhi);
-            if (__any(near)) { const int tf = ray_fix(ray, t, cur, hi, stepx); t = near ? tf : t; }
-            ray_commit(P, ray, t, cur, stepx, xhi, yhi);
-            if (__popcll(__ballot(!ray.active)) >= want_free) break;
+            int n_free = 0;
+            #pragma unroll
+            for (int q = 0; q < FTGP_SLOTS; ++q) {
+                int t, cur, hi, xhi, yhi; bool stepx;
+                const bool near = ray_step(P, ray[q], ah[q], t, cur, hi, stepx, xhi, yhi);
+                if (__any(near)) { const int tf = ray_fix(ray[q], t, cur, hi, stepx); t = near ? tf : t; }
+                ray_commit(P, ray[q], t, cur, stepx, xhi, yhi);
+                n_free += __popcll(__ballot(!ray[q].active));
+            }
+            if (n_free >= want_free) break;
         }
+        (void)n_idle;
     }
     if (P.scan_full) {
         // the row goes to HBM as aligned 16-B-per-lane stores (rows start on 256-B boundaries)
