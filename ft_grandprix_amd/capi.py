@@ -15,7 +15,7 @@ import numpy as np
 
 from .track import Track
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 PATH_POINTS = 100
 MAX_LAP_TIMES = 16
 SNAPSHOT_DOUBLES = 10
@@ -52,14 +52,16 @@ class FtgpVehicle(C.Structure):
                 ("contact_stiffness", C.c_double), ("contact_damping", C.c_double),
                 ("lidar_x", C.c_double), ("lidar_y", C.c_double), ("lidar_ring_radius", C.c_double),
                 ("body_z", C.c_double),
-                ("box_xmin", C.c_double), ("box_xmax", C.c_double), ("box_ymin", C.c_double), ("box_ymax", C.c_double)]
+                ("box_xmin", C.c_double), ("box_xmax", C.c_double), ("box_ymin", C.c_double), ("box_ymax", C.c_double),
+                ("softener_radius", C.c_double)]
 
 
 class FtgpConfig(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("n_envs", C.c_int32), ("cars_per_env", C.c_int32),
                 ("n_rays", C.c_int32), ("lap_target", C.c_int32), ("device_id", C.c_int32),
                 ("spawn_mode", C.c_int32), ("env_base", C.c_int32), ("seed", C.c_uint64),
-                ("dt", C.c_double), ("track", FtgpTrack), ("vehicle", FtgpVehicle)]
+                ("dt", C.c_double), ("bubble_wrap", C.c_int32), ("naive_flatten", C.c_int32),
+                ("track", FtgpTrack), ("vehicle", FtgpVehicle)]
 
 
 # every symbol include/ftgp.h declares (checked by tests/test_capi.py)
@@ -170,7 +172,8 @@ class Env:
 
     def __init__(self, lib: CLib, track: Track, n_envs: int = 1, cars_per_env: int = 1, n_rays: int = 90,
                  lap_target: int = 10, dt: float = 0.004, spawn_mode: int = 0, seed: int = 1234,
-                 device_id: int = 0, vehicle: Optional[FtgpVehicle] = None, env_base: int = 0):
+                 device_id: int = 0, vehicle: Optional[FtgpVehicle] = None, env_base: int = 0,
+                 bubble_wrap: bool = False, naive_flatten: bool = False):
         self.lib, self.track = lib, track
         self.n_envs, self.cars_per_env, self.n_rays = int(n_envs), int(cars_per_env), int(n_rays)
         self.n_cars = self.n_envs * self.cars_per_env
@@ -180,6 +183,7 @@ class Env:
         cfg.n_envs, cfg.cars_per_env, cfg.n_rays = self.n_envs, self.cars_per_env, self.n_rays
         cfg.lap_target, cfg.device_id, cfg.spawn_mode, cfg.seed, cfg.dt = lap_target, device_id, spawn_mode, seed, dt
         cfg.env_base = env_base
+        cfg.bubble_wrap, cfg.naive_flatten = int(bool(bubble_wrap)), int(bool(naive_flatten))
         self.env_base = int(env_base)
         self._bits = np.ascontiguousarray(track.bits, dtype=np.uint32)
         self._path = np.ascontiguousarray(track.path, dtype=np.float64)

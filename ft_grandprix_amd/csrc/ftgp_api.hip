@@ -71,19 +71,21 @@ struct FtgpEnv {
     hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_metrics = nullptr;
     bool timed = false;
     // device buffers
-    uint8_t* d_coarse = nullptr; uint2* d_rank = nullptr; uint8_t* d_fine = nullptr; uint32_t* d_field = nullptr;
+    uint16_t* d_field = nullptr; uint32_t* d_bits = nullptr; uint32_t* d_nearbits = nullptr;
     double* d_path = nullptr; double* d_spawn = nullptr; float* d_ray = nullptr; void* d_veh = nullptr; DeviceParams* d_params = nullptr;
     CarState* d_cars = nullptr; float* d_ranges = nullptr; int64_t* d_steps = nullptr;
     uint8_t* d_env_mask = nullptr; uint8_t* d_car_mask = nullptr; double* d_ctrl = nullptr; double* d_pose = nullptr;
     double* d_metrics = nullptr; double* d_gather = nullptr;
-    std::vector<CarState> h_cars;
-    int cars_per_block = 4;
+    int32_t* d_prog = nullptr; double* d_core = nullptr;
+    std::vector<int32_t> h_prog; std::vector<double> h_core;
     bool multi = false;
     // comm
     void* comm = nullptr; int rank = 0, world = 1;
 };
 
 namespace {
+
+constexpr int kCoreDoubles = 16;     // row of ftgp_pack_kernel
 
 // exact chessboard distance transform of a W x H occupancy image (two raster sweeps over a padded image)
 void chessboard_dt(const std::vector<uint8_t>& occ, int W, int H, std::vector<int>& out)
@@ -108,34 +110,30 @@ void chessboard_dt(const std::vector<uint8_t>& occ, int W, int H, std::vector<in
         for (int x = 0; x < W; ++x) out[(size_t)y * W + x] = at(x, y);
 }
 
-// Two-level wall grid over 8x8-pixel blocks:
-//   fine   : for every non-empty block (row-major block order) 64 nibbles = chessboard distance in pixels from each
-//            of its pixels to the nearest wall pixel anywhere (0 = wall; at most 7 because the block holds a wall)
-//   rank   : per 32 blocks {non-empty bits, number of non-empty blocks before the word} -> index into fine
-//   coarse : one nibble per block = chessboard distance in blocks to the nearest non-empty block, clamped to 15
-struct HostGrid {
+// Host-side inputs of the octant box field (the boxes themselves are searched on the GPU, ftgp_box_field_kernel) and the
+// bitmaps of the wall contact.
+struct HostTables {
+    std::vector<uint8_t> wall;        // [H][W] 1 = wall
     std::vector<uint8_t> ksq;         // [4][H][W] largest wall-free forward square per quadrant (clamp 255)
     std::vector<uint16_t> runx, runy; // [2][H][W] wall-free run lengths along +x / -x and +y / -y (65535 = beyond the image)
-    int nbx = 0, nby = 0, nwpr = 0, n_fine = 0;
-    std::vector<uint8_t> coarse;
-    std::vector<uint2> rank;
-    std::vector<uint8_t> fine;
+    std::vector<uint32_t> bits, nearbits;   // [H][wpr], padding bits clear
 };
 
-void build_grid(const FtgpTrack& t, HostGrid& g)
+void build_tables(const FtgpTrack& t, int reach, HostTables& g)
 {
-    const int W = t.width, H = t.height;
-    g.nbx = (W + 7) >> 3; g.nby = (H + 7) >> 3; g.nwpr = (g.nbx + 31) >> 5;
-    std::vector<uint8_t> wall((size_t)W * H, 0), nonempty((size_t)g.nbx * g.nby, 0);
+    const int W = t.width, H = t.height, wpr = t.words_per_row;
+    g.wall.assign((size_t)W * H, 0);
+    g.bits.assign((size_t)H * wpr, 0u); g.nearbits.assign((size_t)H * wpr, 0u);
     for (int y = 0; y < H; ++y)
         for (int x = 0; x < W; ++x)
-            if ((t.bits[(size_t)y * t.words_per_row + (x >> 5)] >> (x & 31)) & 1u) {
-                wall[(size_t)y * W + x] = 1; nonempty[(size_t)(y >> 3) * g.nbx + (x >> 3)] = 1;
+            if ((t.bits[(size_t)y * wpr + (x >> 5)] >> (x & 31)) & 1u) {
+                g.wall[(size_t)y * W + x] = 1; g.bits[(size_t)y * wpr + (x >> 5)] |= 1u << (x & 31);
             }
-    std::vector<int> dpx, dblk;
-    chessboard_dt(wall, W, H, dpx);
-    chessboard_dt(nonempty, g.nbx, g.nby, dblk);
-    // inputs of the octant field (the rectangles themselves are searched on the GPU, ftgp_octant_field_kernel):
+    std::vector<int> dpx;
+    chessboard_dt(g.wall, W, H, dpx);
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x)
+            if (dpx[(size_t)y * W + x] <= reach) g.nearbits[(size_t)y * wpr + (x >> 5)] |= 1u << (x & 31);
     //   ksq[q](x, y) = side of the largest wall-free square of pixels with its corner at (x, y), extending towards
     //   (q&1 ? -x : +x, q&2 ? -y : +y); pixels beyond the image count as free; 0 on walls.  Classic largest-square recurrence.
     const size_t plane = (size_t)W * H;
@@ -151,7 +149,7 @@ void build_grid(const FtgpTrack& t, HostGrid& g)
                 for (int xx = 0; xx < W; ++xx) {
                     const int x = sx > 0 ? W - 1 - xx : xx;
                     int v = 0;
-                    if (!wall[(size_t)y * W + x]) v = 1 + std::min(std::min(cur[(size_t)(x + sx + 1)], prev[(size_t)(x + 1)]), prev[(size_t)(x + sx + 1)]);
+                    if (!g.wall[(size_t)y * W + x]) v = 1 + std::min(std::min(cur[(size_t)(x + sx + 1)], prev[(size_t)(x + 1)]), prev[(size_t)(x + sx + 1)]);
                     cur[(size_t)(x + 1)] = v;
                     g.ksq[(size_t)q * plane + (size_t)y * W + x] = (uint8_t)std::min(255, v);
                 }
@@ -162,91 +160,73 @@ void build_grid(const FtgpTrack& t, HostGrid& g)
     g.runx.assign(2 * plane, 0); g.runy.assign(2 * plane, 0);
     for (int y = 0; y < H; ++y) {
         int r = 65535;
-        for (int x = W - 1; x >= 0; --x) { r = wall[(size_t)y * W + x] ? 0 : std::min(65535, r + 1); g.runx[(size_t)y * W + x] = (uint16_t)r; }
+        for (int x = W - 1; x >= 0; --x) { r = g.wall[(size_t)y * W + x] ? 0 : std::min(65535, r + 1); g.runx[(size_t)y * W + x] = (uint16_t)r; }
         r = 65535;
-        for (int x = 0; x < W; ++x) { r = wall[(size_t)y * W + x] ? 0 : std::min(65535, r + 1); g.runx[plane + (size_t)y * W + x] = (uint16_t)r; }
+        for (int x = 0; x < W; ++x) { r = g.wall[(size_t)y * W + x] ? 0 : std::min(65535, r + 1); g.runx[plane + (size_t)y * W + x] = (uint16_t)r; }
     }
     for (int x = 0; x < W; ++x) {
         int r = 65535;
-        for (int y = H - 1; y >= 0; --y) { r = wall[(size_t)y * W + x] ? 0 : std::min(65535, r + 1); g.runy[(size_t)y * W + x] = (uint16_t)r; }
+        for (int y = H - 1; y >= 0; --y) { r = g.wall[(size_t)y * W + x] ? 0 : std::min(65535, r + 1); g.runy[(size_t)y * W + x] = (uint16_t)r; }
         r = 65535;
-        for (int y = 0; y < H; ++y) { r = wall[(size_t)y * W + x] ? 0 : std::min(65535, r + 1); g.runy[plane + (size_t)y * W + x] = (uint16_t)r; }
+        for (int y = 0; y < H; ++y) { r = g.wall[(size_t)y * W + x] ? 0 : std::min(65535, r + 1); g.runy[plane + (size_t)y * W + x] = (uint16_t)r; }
     }
-    g.rank.assign((size_t)g.nby * g.nwpr, make_uint2(0u, 0u));
-    g.fine.clear(); g.n_fine = 0;
-    for (int by = 0; by < g.nby; ++by)
-        for (int w = 0; w < g.nwpr; ++w) {
-            uint2 r = make_uint2(0u, (unsigned)g.n_fine);
-            for (int k = 0; k < 32; ++k) {
-                const int bx = w * 32 + k;
-                if (bx >= g.nbx || !nonempty[(size_t)by * g.nbx + bx]) continue;
-                r.x |= 1u << k;
-                uint8_t img[32] = { 0 };
-                for (int n = 0; n < 64; ++n) {
-                    const int x = bx * 8 + (n & 7), y = by * 8 + (n >> 3);
-                    // pixels beyond the image edge are never queried (the march leaves the image first); mark them distance 1
-                    const int dv = (x < W && y < H) ? std::min(15, dpx[(size_t)y * W + x]) : 1;
-                    img[n >> 1] |= (uint8_t)(dv << ((n & 1) << 2));
-                }
-                g.fine.insert(g.fine.end(), img, img + 32);
-                g.n_fine += 1;
-            }
-            g.rank[(size_t)by * g.nwpr + w] = r;
-        }
-    g.coarse.assign(((size_t)g.nbx * g.nby + 1) / 2, 0);
-    for (int q = 0; q < g.nbx * g.nby; ++q)
-        g.coarse[(size_t)q >> 1] |= (uint8_t)(std::min(15, dblk[(size_t)q]) << ((q & 1) << 2));
 }
 
 inline int pad16(size_t n) { return (int)((n + 15) & ~(size_t)15); }
 
-// LDS layout for `cpb` cars per workgroup; returns the total
-int lds_layout(DeviceParams& P, int cpb)
+// LDS layout for `cpb` cars and `wpb` waves per workgroup; returns the total
+int lds_layout(DeviceParams& P, int cpb, int wpb)
 {
     int o = 0;
     P.off_params = o; o += pad16(sizeof(DeviceParams));
     P.off_veh = o;    o += pad16(sizeof(VehLds));
-    P.off_fine = o;   o += P.use_field ? 0 : std::max(16, pad16((size_t)P.n_fine * 32));
-    P.off_rank = o;   o += P.use_field ? 0 : pad16((size_t)P.nby * P.nwpr * 8);
     P.off_path = o;   o += pad16(sizeof(double) * 2 * FTGP_PATH_POINTS);
-    P.off_coarse = o; o += P.use_field ? 0 : pad16(((size_t)P.nbx * P.nby + 1) / 2);
-    P.off_ray = o;    o += 2 * P.ray_floats * (int)sizeof(float);
-    P.off_state = o;  o += cpb * (int)sizeof(CarCore);
-    P.off_next = o;   o += pad16((size_t)cpb * sizeof(Dyn));
-    P.off_scan = o;   o += cpb * P.scan_floats * (int)sizeof(float);
+    P.off_ray = o;    o += pad16(sizeof(float) * 2 * (size_t)P.n_rays);
+    P.off_cars = o;   o += cpb * (int)sizeof(CarCore);
+    P.off_frame = o;  o += cpb * (int)sizeof(LidarFrame);
+    P.off_steps = o;  o += pad16((size_t)cpb * sizeof(int64_t));
+    P.off_scan = o;   o += cpb * P.win_floats * (int)sizeof(float);
+    P.off_list = o;   o += wpb * FTGP_WAVE * (int)sizeof(int);
+    P.off_pool = o;   o += 16;
     P.lds_bytes = o;
+    P.cars_per_block = cpb; P.waves_per_block = wpb;
     return o;
-}
-
-int sync_cars_to_host(FtgpEnv* e)
-{
-    HIP_TRY(hipSetDevice(e->device));
-    e->h_cars.resize((size_t)e->P.n_cars);
-    HIP_TRY(hipMemcpyAsync(e->h_cars.data(), e->d_cars, sizeof(CarState) * (size_t)e->P.n_cars, hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
-    return 0;
 }
 
 int launch_steps(FtgpEnv* e, int policy, int n_steps)
 {
     if (n_steps < 0) return fail(FTGP_ERR_ARG, "n_steps < 0%s");
-    if ((policy == FTGP_POLICY_NIDC || policy == FTGP_POLICY_FAST) && e->P.n_rays < 8)
-        return fail(FTGP_ERR_ARG, "nidc/fast need n_rays >= 8 (they drop len/8 rays from each end)%s");
+    if (policy == FTGP_POLICY_NIDC || policy == FTGP_POLICY_FAST) {
+        if (e->P.n_rays < 8) return fail(FTGP_ERR_ARG, "nidc/fast need n_rays >= 8 (they drop len/8 rays from each end)%s");
+        if (e->P.n_rays - 2 * e->P.eighth > FTGP_WAVE * FTGP_WAVE) return fail(FTGP_ERR_ARG, "the device drivers handle at most 4096 samples in the front window%s");
+    }
     HIP_TRY(hipSetDevice(e->device));
-    const int cpb = e->cars_per_block;
+    const int cpb = e->P.cars_per_block;
     const int blocks = (e->P.n_cars + cpb - 1) / cpb;
     HIP_TRY(hipEventRecord(e->ev_start, e->stream));
     if (n_steps > 0) {
-        const dim3 grid(blocks), block(cpb * FTGP_WAVE);
+        const dim3 grid(blocks), block(e->P.waves_per_block * FTGP_WAVE);
         const size_t lds = (size_t)e->P.lds_bytes;
-        if (e->multi && e->P.use_field) hipLaunchKernelGGL((ftgp_step_kernel<true, true>), grid, block, lds, e->stream, e->d_params, policy, n_steps, cpb);
-        else if (e->multi)              hipLaunchKernelGGL((ftgp_step_kernel<true, false>), grid, block, lds, e->stream, e->d_params, policy, n_steps, cpb);
-        else if (e->P.use_field)        hipLaunchKernelGGL((ftgp_step_kernel<false, true>), grid, block, lds, e->stream, e->d_params, policy, n_steps, cpb);
-        else                            hipLaunchKernelGGL((ftgp_step_kernel<false, false>), grid, block, lds, e->stream, e->d_params, policy, n_steps, cpb);
+        if (e->multi) hipLaunchKernelGGL((ftgp_step_kernel<true>), grid, block, lds, e->stream, e->d_params, policy, n_steps);
+        else          hipLaunchKernelGGL((ftgp_step_kernel<false>), grid, block, lds, e->stream, e->d_params, policy, n_steps);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(e->ev_stop, e->stream));
     e->timed = true;
+    return 0;
+}
+
+// packed read-back rows (one small kernel + two small copies instead of the whole state records)
+int sync_rows_to_host(FtgpEnv* e)
+{
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t n = (size_t)e->P.n_cars;
+    e->h_prog.resize(n * FTGP_PROGRESS_INTS); e->h_core.resize(n * kCoreDoubles);
+    hipLaunchKernelGGL(ftgp_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, e->P, e->d_prog, e->d_core);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(e->h_prog.data(), e->d_prog, sizeof(int32_t) * e->h_prog.size(), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->h_core.data(), e->d_core, sizeof(double) * e->h_core.size(), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
     return 0;
 }
 
@@ -282,6 +262,7 @@ void ftgp_default_vehicle(FtgpVehicle* v)
     v->lidar_x = -0.0525; v->lidar_y = 0.0; v->lidar_ring_radius = 0.03;       // (:101-103)
     v->body_z = 0.0156;
     v->box_xmin = -0.1027; v->box_xmax = 0.1034; v->box_ymin = -0.0461; v->box_ymax = 0.0472;   // STL bbox x 0.5
+    v->softener_radius = 0.65 * 0.0488;                                        // mushr_wheel.stl radius x (mushr_scale * 1.3) (:39,65-67)
 }
 
 const char* ftgp_last_error(void) { return g_err; }
@@ -300,8 +281,8 @@ int ftgp_destroy(FtgpEnv* e)
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->side) (void)hipStreamSynchronize(e->side);
     if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
-    void* bufs[] = { e->d_field, e->d_params, e->d_veh, e->d_coarse, e->d_rank, e->d_fine, e->d_path, e->d_spawn, e->d_ray, e->d_cars, e->d_ranges,
-                     e->d_steps, e->d_env_mask, e->d_car_mask, e->d_ctrl, e->d_pose, e->d_metrics, e->d_gather };
+    void* bufs[] = { e->d_field, e->d_bits, e->d_nearbits, e->d_params, e->d_veh, e->d_path, e->d_spawn, e->d_ray, e->d_cars, e->d_ranges,
+                     e->d_steps, e->d_env_mask, e->d_car_mask, e->d_ctrl, e->d_pose, e->d_metrics, e->d_gather, e->d_prog, e->d_core };
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (e->ev_start) (void)hipEventDestroy(e->ev_start);
     if (e->ev_stop) (void)hipEventDestroy(e->ev_stop);
@@ -324,8 +305,12 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
     const FtgpTrack& t = cfg->track;
     if (t.width < 1 || t.height < 1 || !t.bits || !t.path || t.words_per_row < (t.width + 31) / 32)
         return fail(FTGP_ERR_ARG, "bad track%s");
+    if (t.width > 8192 || t.height > 8192) return fail(FTGP_ERR_ARG, "images above 8192 pixels are not supported%s");
     if (cfg->env_base < 0) return fail(FTGP_ERR_ARG, "env_base < 0%s");
     if (!(cfg->dt > 0.0) || !(t.px_size_x > 0.0) || !(t.px_size_y > 0.0)) return fail(FTGP_ERR_ARG, "bad dt / pixel size%s");
+    const FtgpVehicle& v = cfg->vehicle;
+    if (!(v.contact_radius > 0.0) || !(v.mass > 0.0) || !(v.izz > 0.0)) return fail(FTGP_ERR_ARG, "bad vehicle%s");
+    if (cfg->bubble_wrap && !(v.softener_radius > 0.0)) return fail(FTGP_ERR_ARG, "bubble_wrap needs vehicle.softener_radius > 0%s");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return fail(FTGP_ERR_NO_DEVICE, "no HIP device: this library has no CPU fallback%s");
@@ -353,14 +338,15 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
     DeviceParams& P = e->P;
     P.n_envs = cfg->n_envs; P.cars_per_env = cfg->cars_per_env; P.n_cars = cfg->n_envs * cfg->cars_per_env;
     P.n_rays = cfg->n_rays; P.lap_target = cfg->lap_target; P.spawn_mode = cfg->spawn_mode; P.env_base = cfg->env_base;
-    P.ranges_stride = (cfg->n_rays + 63) & ~63;      // rows start on 256-B boundaries: every pass is one aligned store
+    P.ranges_stride = (cfg->n_rays + 31) & ~31;      // rows start on 128-B boundaries
     P.seed = cfg->seed; P.dt = cfg->dt;
-    P.width = t.width; P.height = t.height; P.words_per_row = t.words_per_row;
+    P.bubble_wrap = cfg->bubble_wrap ? 1 : 0;        // cfg->naive_flatten: accepted, no effect on a planar model (custom.py:1338-1339)
+    P.width = t.width; P.height = t.height; P.words_per_row = t.words_per_row; P.fstride = t.width + 2;
+    P.plane_bytes = 2u * (uint32_t)(t.width + 2) * (uint32_t)(t.height + 2);
     P.px_size_x = t.px_size_x; P.px_size_y = t.px_size_y; P.origin_x = t.origin_x; P.origin_y = t.origin_y;
     P.inv_px_x = 1.0 / t.px_size_x; P.inv_px_y = 1.0 / t.px_size_y;
     P.inv_px_x_f = (float)P.inv_px_x; P.inv_px_y_f = (float)P.inv_px_y;
     P.veh = cfg->vehicle;
-    const FtgpVehicle& v = cfg->vehicle;
     {   // static wheel loads from the wheelbase split
         const double a_f = 0.5 * (v.wheel_x[0] + v.wheel_x[1]), a_r = -0.5 * (v.wheel_x[2] + v.wheel_x[3]);
         const double wtot = v.mass * v.gravity;
@@ -368,26 +354,54 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
         P.wheel_load[2] = P.wheel_load[3] = 0.5 * (wtot * (a_f / (a_f + a_r)));
     }
     e->multi = cfg->cars_per_env > 1;
+    {   // chessboard reach of the largest wall-contact window
+        const double rmax = std::max(v.contact_radius, cfg->bubble_wrap ? v.softener_radius : 0.0);
+        P.contact_reach = std::max((int)ceil(rmax * P.inv_px_x), (int)ceil(rmax * P.inv_px_y));
+    }
+    P.eighth = (int)((double)cfg->n_rays / 8.0);                    // nidc.py:18
+    P.win_floats = (1 + (cfg->n_rays - 2 * P.eighth) + 3) & ~3;
+    P.snap_eps = 1.0f / 512.0f;
+    P.ray_magic = (uint32_t)((0x100000000ull + (uint64_t)cfg->n_rays - 1) / (uint64_t)cfg->n_rays);
+
+    // workgroup shape: whole envs, at most 16 cars (K1 / K3 run on the lanes of one wave), two workgroups per CU
+    // (<= 80 KiB of LDS each) so that 8 waves per SIMD hide the latency of the field loads
+    {
+        const int unit = cfg->cars_per_env;
+        int wpb = 16;
+        if (const char* sv = getenv("FTGP_WAVES_PER_BLOCK")) { const int c = atoi(sv); if (c >= 1 && c <= 16) wpb = c; }
+        int want = (FTGP_MAX_CARS_PER_BLOCK / unit) * unit;
+        // small batches: fewer cars per workgroup so that every CU gets two workgroups (256 CUs)
+        const int n_units = P.n_cars / unit;
+        const int spread = std::max(1, n_units / 512) * unit;
+        int cpb = std::min(want, spread);
+        if (const char* sv = getenv("FTGP_CARS_PER_BLOCK")) { const int c = atoi(sv); if (c >= unit && c <= FTGP_MAX_CARS_PER_BLOCK) cpb = (c / unit) * unit; }
+        int lds_cap = 80 * 1024;
+        if (const char* sv = getenv("FTGP_LDS_CAP_KB")) { const int c = atoi(sv); if (c >= 16 && c <= 160) lds_cap = c * 1024; }
+        while (cpb > unit && lds_layout(P, cpb, wpb) > lds_cap) cpb -= unit;
+        if (lds_layout(P, cpb, wpb) > 160 * 1024) {
+            snprintf(g_err, sizeof g_err, "one env of %d car(s) with a %d-ray scan does not fit the 160 KiB LDS", unit, P.n_rays);
+            ftgp_destroy(e);
+            return FTGP_ERR_ARG;
+        }
+        // pool index -> car slot by multiplication: exact for every index the sweep can produce
+        for (uint32_t g = 0; g < (uint32_t)(cpb * P.n_rays); ++g)
+            if ((uint32_t)(((uint64_t)g * P.ray_magic) >> 32) != g / (uint32_t)P.n_rays) {
+                snprintf(g_err, sizeof g_err, "internal: ray_magic is not exact for n_rays = %d", P.n_rays);
+                ftgp_destroy(e);
+                return FTGP_ERR_ARG;
+            }
+    }
+    CREATE_TRY(hipFuncSetAttribute((const void*)ftgp_step_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CREATE_TRY(hipFuncSetAttribute((const void*)ftgp_step_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 
     // host-side tables
-    HostGrid grid;
-    build_grid(t, grid);
-    P.nbx = grid.nbx; P.nby = grid.nby; P.nwpr = grid.nwpr; P.n_fine = grid.n_fine;
-    P.eighth = (int)((double)cfg->n_rays / 8.0);                    // nidc.py:18
-    P.scan_floats = (1 + (cfg->n_rays - 2 * P.eighth) + 3) & ~3;
-    P.ray_floats = (cfg->n_rays + 3) & ~3;
-    P.snap_eps = 1.0f / 512.0f;
-    P.use_field = 1;                                                // default: flat per-pixel field from L2 (fewest instructions per march iteration)
-    if (const char* sv = getenv("FTGP_FIELD")) { if (!strcmp(sv, "lds")) P.use_field = 0; else if (!strcmp(sv, "global")) P.use_field = 1; }
-    P.scan_full = P.use_field;                                      // LDS has room for whole rows only without the wall grid
-    if (P.scan_full) P.scan_floats = P.ray_floats;
-    if (t.width > 8192 || t.height > 8192) { snprintf(g_err, sizeof g_err, "images above 8192 pixels are not supported"); ftgp_destroy(e); return FTGP_ERR_ARG; }
-    const int scan_floats = P.ray_floats;
-    std::vector<float> ray(2 * (size_t)scan_floats, 0.0f);
+    HostTables tab;
+    build_tables(t, P.contact_reach, tab);
+    std::vector<float> ray(2 * (size_t)cfg->n_rays + 4, 0.0f);
     for (int j = 0; j < cfg->n_rays; ++j) {
         // mushr.em.xml:112-117: phi_j = radians(360/R*j - 90); the ray (+z of the site) is (sin phi, -cos phi, 0)
         const double phi = ((360.0 / (double)cfg->n_rays) * (double)j - 90.0) * (M_PI / 180.0);
-        ray[(size_t)j] = (float)sin(phi); ray[(size_t)scan_floats + j] = (float)(-cos(phi));
+        ray[2 * (size_t)j] = (float)sin(phi); ray[2 * (size_t)j + 1] = (float)(-cos(phi));
     }
     std::vector<double> spawn(4 * FTGP_PATH_POINTS);
     for (int p = 0; p < FTGP_PATH_POINTS; ++p) {
@@ -398,47 +412,18 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
         spawn[4 * p + 2] = cos(ang / 2); spawn[4 * p + 3] = sin(ang / 2);
     }
 
-    // cars (waves) per workgroup: as many as fit the 160 KiB of LDS next to the track, at most 16 (one workgroup per CU)
-    {
-        const int unit = e->multi ? cfg->cars_per_env : 1;
-        // multi-car envs synchronise with workgroup barriers twice per step: with the flat field (no per-workgroup track copy
-        // in LDS) one env per workgroup keeps that wait among the cars that actually interact (measured: -14 %)
-        int want = (e->multi && P.use_field) ? unit : 16;
-        if (const char* sv = getenv("FTGP_CARS_PER_BLOCK")) { const int c = atoi(sv); if (c >= 1 && c <= 16) want = c; }
-        // small batches: fewer cars per workgroup so that every CU gets work (256 CUs)
-        const int n_units = P.n_cars / unit;
-        const int spread = std::max(1, n_units / 256) * unit;
-        int cpb = std::min((want / unit) * unit, std::max(unit, spread));
-        if (getenv("FTGP_CARS_PER_BLOCK")) cpb = (want / unit) * unit;
-        while (cpb >= unit && lds_layout(P, cpb) > 160 * 1024) cpb -= unit;
-        if (cpb < unit) {
-            snprintf(g_err, sizeof g_err, "track grid (%d non-empty 8x8 blocks of %dx%d) + %d-ray scan do not fit the 160 KiB LDS",
-                     P.n_fine, P.nbx, P.nby, P.n_rays);
-            ftgp_destroy(e);
-            return FTGP_ERR_ARG;
-        }
-        e->cars_per_block = cpb;
-        lds_layout(P, cpb);
-    }
-    CREATE_TRY(hipFuncSetAttribute((const void*)ftgp_step_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    CREATE_TRY(hipFuncSetAttribute((const void*)ftgp_step_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    CREATE_TRY(hipFuncSetAttribute((const void*)ftgp_step_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    CREATE_TRY(hipFuncSetAttribute((const void*)ftgp_step_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-
-    const size_t sz_fine = (size_t)std::max(16, pad16((size_t)P.n_fine * 32)), sz_rank = (size_t)pad16((size_t)P.nby * P.nwpr * 8);
-    const size_t sz_path = (size_t)pad16(sizeof(double) * 2 * FTGP_PATH_POINTS), sz_coarse = (size_t)pad16(((size_t)P.nbx * P.nby + 1) / 2);
-    const size_t sz_ray = (size_t)(P.off_state - P.off_ray);
-    {   // octant field: upload the squares and run lengths, search the rectangles on the device
+    {   // octant box field: upload the squares and run lengths, search the boxes on the device
         const size_t plane = (size_t)t.width * t.height;
+        const size_t cells = (size_t)(t.width + 2) * (t.height + 2) * FTGP_OCTANTS;
         uint8_t* d_ksq = nullptr; uint16_t* d_runx = nullptr; uint16_t* d_runy = nullptr;
-        CREATE_TRY(hipMalloc(&e->d_field, 2 * plane * sizeof(uint32_t)));
+        CREATE_TRY(hipMalloc(&e->d_field, cells * sizeof(uint16_t)));
         CREATE_TRY(hipMalloc(&d_ksq, 4 * plane));
         CREATE_TRY(hipMalloc(&d_runx, 2 * plane * sizeof(uint16_t)));
         CREATE_TRY(hipMalloc(&d_runy, 2 * plane * sizeof(uint16_t)));
-        CREATE_TRY(hipMemcpy(d_ksq, grid.ksq.data(), 4 * plane, hipMemcpyHostToDevice));
-        CREATE_TRY(hipMemcpy(d_runx, grid.runx.data(), 2 * plane * sizeof(uint16_t), hipMemcpyHostToDevice));
-        CREATE_TRY(hipMemcpy(d_runy, grid.runy.data(), 2 * plane * sizeof(uint16_t), hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(ftgp_octant_field_kernel, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, e->stream, d_ksq, d_runx, d_runy, t.width, t.height, e->d_field);
+        CREATE_TRY(hipMemcpy(d_ksq, tab.ksq.data(), 4 * plane, hipMemcpyHostToDevice));
+        CREATE_TRY(hipMemcpy(d_runx, tab.runx.data(), 2 * plane * sizeof(uint16_t), hipMemcpyHostToDevice));
+        CREATE_TRY(hipMemcpy(d_runy, tab.runy.data(), 2 * plane * sizeof(uint16_t), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(ftgp_box_field_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, e->stream, d_ksq, d_runx, d_runy, t.width, t.height, e->d_field);
         CREATE_TRY(hipGetLastError());
         CREATE_TRY(hipStreamSynchronize(e->stream));
         (void)hipFree(d_ksq); (void)hipFree(d_runx); (void)hipFree(d_runy);
@@ -446,39 +431,50 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
     }
     {
         std::vector<unsigned char> vimg((size_t)pad16(sizeof(VehLds)), 0);
-        VehLds vl; vl.v = P.veh; for (int i = 0; i < 4; ++i) vl.wheel_load[i] = P.wheel_load[i];
+        VehLds vl; memset(&vl, 0, sizeof vl);
+        vl.v = P.veh; for (int i = 0; i < 4; ++i) vl.wheel_load[i] = P.wheel_load[i];
+        // every part of a car that a ray can see (chassis box, LiDAR puck) lies within rmax of the car's origin; 10 % margin
+        const double cx = std::max(fabs(v.box_xmin), fabs(v.box_xmax)), cy = std::max(fabs(v.box_ymin), fabs(v.box_ymax));
+        const double rmax = std::max(sqrt(cx * cx + cy * cy), sqrt(v.lidar_x * v.lidar_x + v.lidar_y * v.lidar_y) + v.lidar_ring_radius);
+        vl.cull_radius = (float)(1.1 * rmax);
         memcpy(vimg.data(), &vl, sizeof vl);
         CREATE_TRY(hipMalloc(&e->d_veh, vimg.size()));
         CREATE_TRY(hipMemcpy(e->d_veh, vimg.data(), vimg.size(), hipMemcpyHostToDevice));
         P.veh_dev = e->d_veh;
     }
-    CREATE_TRY(hipMalloc(&e->d_fine, sz_fine));
-    CREATE_TRY(hipMalloc(&e->d_rank, sz_rank));
+    const size_t sz_bits = sizeof(uint32_t) * (size_t)t.height * t.words_per_row;
+    const size_t sz_path = (size_t)pad16(sizeof(double) * 2 * FTGP_PATH_POINTS), sz_ray = (size_t)pad16(sizeof(float) * 2 * (size_t)cfg->n_rays);
+    const size_t n_cars = (size_t)P.n_cars;
+    CREATE_TRY(hipMalloc(&e->d_bits, sz_bits));
+    CREATE_TRY(hipMalloc(&e->d_nearbits, sz_bits));
     CREATE_TRY(hipMalloc(&e->d_path, sz_path));
-    CREATE_TRY(hipMalloc(&e->d_coarse, sz_coarse));
     CREATE_TRY(hipMalloc(&e->d_ray, sz_ray));
     CREATE_TRY(hipMalloc(&e->d_spawn, sizeof(double) * 4 * FTGP_PATH_POINTS));
-    CREATE_TRY(hipMalloc(&e->d_cars, sizeof(CarState) * (size_t)P.n_cars));
-    CREATE_TRY(hipMalloc(&e->d_ranges, sizeof(float) * (size_t)P.n_cars * P.ranges_stride));
+    CREATE_TRY(hipMalloc(&e->d_cars, sizeof(CarState) * n_cars));
+    CREATE_TRY(hipMalloc(&e->d_ranges, sizeof(float) * n_cars * P.ranges_stride));
     CREATE_TRY(hipMalloc(&e->d_steps, sizeof(int64_t) * (size_t)P.n_envs));
     CREATE_TRY(hipMalloc(&e->d_env_mask, (size_t)P.n_envs));
-    CREATE_TRY(hipMalloc(&e->d_car_mask, (size_t)P.n_cars));
-    CREATE_TRY(hipMalloc(&e->d_ctrl, sizeof(double) * 2 * (size_t)P.n_cars));
-    CREATE_TRY(hipMalloc(&e->d_pose, sizeof(double) * FTGP_POSE_DOUBLES * (size_t)P.n_cars));
+    CREATE_TRY(hipMalloc(&e->d_car_mask, n_cars));
+    CREATE_TRY(hipMalloc(&e->d_ctrl, sizeof(double) * 2 * n_cars));
+    CREATE_TRY(hipMalloc(&e->d_pose, sizeof(double) * FTGP_POSE_DOUBLES * n_cars));
     CREATE_TRY(hipMalloc(&e->d_metrics, sizeof(double) * FTGP_METRIC_DOUBLES));
-    CREATE_TRY(hipMemset(e->d_fine, 0, sz_fine));
-    CREATE_TRY(hipMemset(e->d_rank, 0, sz_rank));
-    CREATE_TRY(hipMemset(e->d_coarse, 0, sz_coarse));
-    if (!grid.fine.empty()) CREATE_TRY(hipMemcpy(e->d_fine, grid.fine.data(), grid.fine.size(), hipMemcpyHostToDevice));
-    CREATE_TRY(hipMemcpy(e->d_rank, grid.rank.data(), grid.rank.size() * sizeof(uint2), hipMemcpyHostToDevice));
-    CREATE_TRY(hipMemcpy(e->d_coarse, grid.coarse.data(), grid.coarse.size(), hipMemcpyHostToDevice));
+    CREATE_TRY(hipMalloc(&e->d_prog, sizeof(int32_t) * FTGP_PROGRESS_INTS * n_cars));
+    CREATE_TRY(hipMalloc(&e->d_core, sizeof(double) * kCoreDoubles * n_cars));
+    CREATE_TRY(hipMemcpy(e->d_bits, tab.bits.data(), sz_bits, hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemcpy(e->d_nearbits, tab.nearbits.data(), sz_bits, hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemsetAsync(e->d_path, 0, sz_path, e->stream));
+    CREATE_TRY(hipStreamSynchronize(e->stream));
     CREATE_TRY(hipMemcpy(e->d_path, t.path, sizeof(double) * 2 * FTGP_PATH_POINTS, hipMemcpyHostToDevice));
     CREATE_TRY(hipMemcpy(e->d_spawn, spawn.data(), sizeof(double) * spawn.size(), hipMemcpyHostToDevice));
-    CREATE_TRY(hipMemcpy(e->d_ray, ray.data(), sizeof(float) * ray.size(), hipMemcpyHostToDevice));
-    CREATE_TRY(hipMemset(e->d_ranges, 0, sizeof(float) * (size_t)P.n_cars * P.ranges_stride));
-    CREATE_TRY(hipMemset(e->d_steps, 0, sizeof(int64_t) * (size_t)P.n_envs));
-    P.coarse = e->d_coarse; P.rank = e->d_rank; P.fine = e->d_fine; P.path = e->d_path; P.spawn = e->d_spawn;
-    P.ray_bx = e->d_ray; P.ray_by = e->d_ray + scan_floats; P.cars = e->d_cars; P.ranges = e->d_ranges; P.steps = e->d_steps;
+    CREATE_TRY(hipMemsetAsync(e->d_ray, 0, sz_ray, e->stream));
+    CREATE_TRY(hipStreamSynchronize(e->stream));
+    CREATE_TRY(hipMemcpy(e->d_ray, ray.data(), sizeof(float) * 2 * (size_t)cfg->n_rays, hipMemcpyHostToDevice));
+    // on the handle's own stream: a non-blocking stream is not ordered against the null stream, and ftgp_reset() below runs on it
+    CREATE_TRY(hipMemsetAsync(e->d_cars, 0, sizeof(CarState) * n_cars, e->stream));
+    CREATE_TRY(hipMemsetAsync(e->d_ranges, 0, sizeof(float) * n_cars * P.ranges_stride, e->stream));
+    CREATE_TRY(hipMemsetAsync(e->d_steps, 0, sizeof(int64_t) * (size_t)P.n_envs, e->stream));
+    P.bits = e->d_bits; P.nearbits = e->d_nearbits; P.path = e->d_path; P.spawn = e->d_spawn;
+    P.ray_dir = e->d_ray; P.cars = e->d_cars; P.ranges = e->d_ranges; P.steps = e->d_steps;
     {   // device image of the parameter block (padded to 16 B for the LDS staging copy)
         std::vector<unsigned char> pimg((size_t)pad16(sizeof(DeviceParams)), 0);
         memcpy(pimg.data(), &P, sizeof(DeviceParams));
@@ -548,28 +544,23 @@ int ftgp_get_lidar(FtgpEnv* e, float* out)
     return 0;
 }
 
-static inline int lap_completion_of(const CarState& a) { return a.good_start ? a.completion : -(100 - a.completion); }
-
 int ftgp_get_snapshot(FtgpEnv* e, double* out)
 {
     if (!e || !out) return fail(FTGP_ERR_ARG, "null argument%s");
-    if (int rc = sync_cars_to_host(e)) return rc;
-    std::vector<int64_t> steps((size_t)e->P.n_envs);
-    HIP_TRY(hipMemcpy(steps.data(), e->d_steps, sizeof(int64_t) * steps.size(), hipMemcpyDeviceToHost));
+    if (int rc = sync_rows_to_host(e)) return rc;
     for (int i = 0; i < e->P.n_cars; ++i) {
-        const CarState& a = e->h_cars[(size_t)i];
+        const double* a = e->h_core.data() + (size_t)i * kCoreDoubles;
         double* o = out + (size_t)i * FTGP_SNAPSHOT_DOUBLES;
         // quaternion_to_euler(w, 0, 0, z), custom.py:62-76
-        const double w = a.qw, x = 0.0, y = 0.0, z = a.qz;
+        const double w = a[2], x = 0.0, y = 0.0, z = a[3];
         const double roll = atan2(+2.0 * (w * x + y * z), +1.0 - 2.0 * (x * x + y * y));
         double t2 = +2.0 * (w * y - z * x);
         t2 = t2 > +1.0 ? +1.0 : t2; t2 = t2 < -1.0 ? -1.0 : t2;
         const double pitch = asin(t2);
         const double yaw = atan2(+2.0 * (w * z + x * y), +1.0 - 2.0 * (y * y + z * z));
-        const int lc = lap_completion_of(a);
-        o[0] = a.laps; o[1] = a.vx; o[2] = a.vy; o[3] = 0.0; o[4] = yaw; o[5] = pitch; o[6] = roll;
-        o[7] = lc; o[8] = a.laps * 100 + lc;
-        o[9] = (double)steps[(size_t)(i / e->P.cars_per_env)] / e->P.dt;   // time = steps / timestep, custom.py:1397 (sic)
+        o[0] = a[9]; o[1] = a[4]; o[2] = a[5]; o[3] = 0.0; o[4] = yaw; o[5] = pitch; o[6] = roll;
+        o[7] = a[10]; o[8] = a[11];
+        o[9] = a[12] / e->P.dt;   // time = steps / timestep, custom.py:1397 (sic)
     }
     return 0;
 }
@@ -577,12 +568,12 @@ int ftgp_get_snapshot(FtgpEnv* e, double* out)
 int ftgp_get_pose(FtgpEnv* e, double* out)
 {
     if (!e || !out) return fail(FTGP_ERR_ARG, "null argument%s");
-    if (int rc = sync_cars_to_host(e)) return rc;
+    if (int rc = sync_rows_to_host(e)) return rc;
     for (int i = 0; i < e->P.n_cars; ++i) {
-        const CarState& a = e->h_cars[(size_t)i];
+        const double* a = e->h_core.data() + (size_t)i * kCoreDoubles;
         double* o = out + (size_t)i * FTGP_POSE_DOUBLES;
-        o[0] = a.x; o[1] = a.y; o[2] = e->P.veh.body_z; o[3] = a.qw; o[4] = 0; o[5] = 0; o[6] = a.qz;
-        o[7] = a.vx; o[8] = a.vy; o[9] = 0; o[10] = 0; o[11] = 0; o[12] = a.wz;
+        o[0] = a[0]; o[1] = a[1]; o[2] = e->P.veh.body_z; o[3] = a[2]; o[4] = 0; o[5] = 0; o[6] = a[3];
+        o[7] = a[4]; o[8] = a[5]; o[9] = 0; o[10] = 0; o[11] = 0; o[12] = a[6];
     }
     return 0;
 }
@@ -602,12 +593,14 @@ int ftgp_policy_eval(FtgpEnv* e, int policy, const float* ranges, double* ctrl_o
 {
     if (!e || !ranges) return fail(FTGP_ERR_ARG, "null argument%s");
     if (policy < FTGP_POLICY_LOBOTOMY || policy > FTGP_POLICY_RANDOM) return fail(FTGP_ERR_ARG, "policy_eval: device policies only%s");
-    if ((policy == FTGP_POLICY_NIDC || policy == FTGP_POLICY_FAST) && e->P.n_rays < 8)
-        return fail(FTGP_ERR_ARG, "nidc/fast need n_rays >= 8%s");
+    if (policy == FTGP_POLICY_NIDC || policy == FTGP_POLICY_FAST) {
+        if (e->P.n_rays < 8) return fail(FTGP_ERR_ARG, "nidc/fast need n_rays >= 8%s");
+        if (e->P.n_rays - 2 * e->P.eighth > FTGP_WAVE * FTGP_WAVE) return fail(FTGP_ERR_ARG, "the device drivers handle at most 4096 samples in the front window%s");
+    }
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipMemcpy2DAsync(e->d_ranges, sizeof(float) * (size_t)e->P.ranges_stride, ranges, sizeof(float) * (size_t)e->P.n_rays,
                              sizeof(float) * (size_t)e->P.n_rays, (size_t)e->P.n_cars, hipMemcpyHostToDevice, e->stream));
-    const size_t lds = 4 * ((size_t)e->P.scan_floats * sizeof(float) + sizeof(CarCore));
+    const size_t lds = 4 * ((size_t)e->P.win_floats * sizeof(float) + sizeof(CarCore) + FTGP_WAVE * sizeof(int));
     if (lds > 64 * 1024) return fail(FTGP_ERR_ARG, "scan does not fit LDS%s");
     hipLaunchKernelGGL(ftgp_policy_kernel, dim3((e->P.n_cars + 3) / 4), dim3(256), lds, e->stream, e->P, policy, ctrl_out ? e->d_ctrl : nullptr);
     HIP_TRY(hipGetLastError());
@@ -628,33 +621,28 @@ int ftgp_eval_progress(FtgpEnv* e)
 int ftgp_get_progress(FtgpEnv* e, int32_t* out)
 {
     if (!e || !out) return fail(FTGP_ERR_ARG, "null argument%s");
-    if (int rc = sync_cars_to_host(e)) return rc;
-    for (int i = 0; i < e->P.n_cars; ++i) {
-        const CarState& a = e->h_cars[(size_t)i];
-        int32_t* o = out + (size_t)i * FTGP_PROGRESS_INTS;
-        const int lc = lap_completion_of(a);
-        o[0] = a.laps; o[1] = a.completion; o[2] = lc; o[3] = a.laps * 100 + lc; o[4] = a.finished;
-        o[5] = a.off_track; o[6] = a.start; o[7] = a.good_start; o[8] = a.delta;
-    }
+    if (int rc = sync_rows_to_host(e)) return rc;
+    memcpy(out, e->h_prog.data(), sizeof(int32_t) * e->h_prog.size());
     return 0;
 }
 
 int ftgp_get_lap_times(FtgpEnv* e, int32_t* counts, double* times)
 {
     if (!e || !counts || !times) return fail(FTGP_ERR_ARG, "null argument%s");
-    if (int rc = sync_cars_to_host(e)) return rc;
-    for (int i = 0; i < e->P.n_cars; ++i) {
-        counts[i] = e->h_cars[(size_t)i].n_times;
-        memcpy(times + (size_t)i * FTGP_MAX_LAP_TIMES, e->h_cars[(size_t)i].times, sizeof(double) * FTGP_MAX_LAP_TIMES);
-    }
+    if (int rc = sync_rows_to_host(e)) return rc;
+    for (int i = 0; i < e->P.n_cars; ++i) counts[i] = (int32_t)e->h_core[(size_t)i * kCoreDoubles + 13];
+    HIP_TRY(hipMemcpy2DAsync(times, sizeof(double) * FTGP_MAX_LAP_TIMES, reinterpret_cast<const char*>(e->d_cars) + sizeof(CarCore), sizeof(CarState),   // times[] follows the CarCore head
+                            
+                             sizeof(double) * FTGP_MAX_LAP_TIMES, (size_t)e->P.n_cars, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
     return 0;
 }
 
 int ftgp_get_ctrl(FtgpEnv* e, double* out)
 {
     if (!e || !out) return fail(FTGP_ERR_ARG, "null argument%s");
-    if (int rc = sync_cars_to_host(e)) return rc;
-    for (int i = 0; i < e->P.n_cars; ++i) { out[2 * i] = e->h_cars[(size_t)i].u_speed; out[2 * i + 1] = e->h_cars[(size_t)i].u_steer; }
+    if (int rc = sync_rows_to_host(e)) return rc;
+    for (int i = 0; i < e->P.n_cars; ++i) { out[2 * i] = e->h_core[(size_t)i * kCoreDoubles + 7]; out[2 * i + 1] = e->h_core[(size_t)i * kCoreDoubles + 8]; }
     return 0;
 }
 
@@ -765,8 +753,7 @@ int ftgp_last_kernel_ms(FtgpEnv* e, float* ms)
 const char* ftgp_kernel_name(FtgpEnv* e)
 {
     if (!e) return "ftgp_step_kernel";
-    if (e->multi) return e->P.use_field ? "ftgp_step_kernel<true, true>" : "ftgp_step_kernel<true, false>";
-    return e->P.use_field ? "ftgp_step_kernel<false, true>" : "ftgp_step_kernel<false, false>";
+    return e->multi ? "ftgp_step_kernel<true>" : "ftgp_step_kernel<false>";
 }
 
 }  // extern "C"

@@ -3,11 +3,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/ftgp.h"
+#include "ftgp_march.h"
 
 #define FTGP_WAVE 64
+#define FTGP_MAX_CARS_PER_BLOCK 16      // K1 / K3 run one car per lane group of a single wave: 16 cars x 4 lanes
 
-// Per-car state, array-of-structs in HBM: one wave owns one car in the step kernel and pulls the whole
-// record with a handful of wave-uniform loads (320 B = 2.5 cache lines) instead of ~30 scattered lines.
+// Per-car state, array-of-structs in HBM.  The step kernel keeps CarCore in LDS for the whole launch.
 struct alignas(16) CarCore {
     double x, y, qw, qz;          // planar pose (yaw as quaternion (qw, 0, 0, qz))
     double vx, vy, wz;            // world-frame linear velocity, yaw rate
@@ -20,12 +21,22 @@ struct alignas(16) CarCore {
     int32_t good_start, finished, off_track, delta;
     int32_t n_times, pad0, pad1, pad2;
 };
-// The lap-time list stays in HBM (written on lap crossings only); the step kernel keeps just CarCore in registers.
+// The lap-time list stays in HBM (written on lap crossings only).
 struct alignas(16) CarState : CarCore {
     double times[FTGP_MAX_LAP_TIMES];
 };
 static_assert(sizeof(CarCore) == 192, "CarCore layout");
-static_assert(sizeof(CarState) == 320, "CarState layout");
+static_assert(sizeof(CarState) == 192 + 8 * FTGP_MAX_LAP_TIMES, "CarState layout");
+
+// LiDAR frame of one car, refreshed in LDS before every sweep: the sweep never reads the live state, so the dynamics
+// of the same step can run beside it.  The second half is what OTHER cars of the env need to see this car.
+struct alignas(16) LidarFrame {
+    float u0, v0, chf, shf;       // LiDAR centre in pixels (binary32 of the binary64 value), heading (cos, sin) in binary32
+    double lcx, lcy;              // LiDAR centre, world
+    double x, y, qw, qz;          // pre-step pose
+    int32_t finished, pad0, pad1, pad2;
+};
+static_assert(sizeof(LidarFrame) == 80, "LidarFrame layout");
 
 struct DeviceParams {
     // sizes
@@ -34,36 +45,37 @@ struct DeviceParams {
     uint64_t seed;
     double dt;
     // track
-    int32_t width, height, words_per_row, pad1;
+    int32_t width, height, words_per_row, fstride;      // fstride = width + 2: cells per row of a field plane (one-pixel ring)
     double px_size_x, px_size_y, origin_x, origin_y, inv_px_x, inv_px_y;
     float inv_px_x_f, inv_px_y_f;
-    // two-level wall grid over 8x8-pixel blocks (built on the host at create; staged into LDS by the step kernel)
-    int32_t nbx, nby, nwpr, n_fine;    // blocks per row / column, 32-block words per row, non-empty blocks
-    const uint8_t* coarse;        // 4 bits per block: chessboard distance in BLOCKS to the nearest non-empty block (0 = has walls), clamp 15
-    const uint2* rank;            // [nby][nwpr] {non-empty bits of 32 blocks, number of non-empty blocks before this word}
-    const uint8_t* fine;          // [n_fine][32] 4 bits per pixel of each non-empty block: chessboard distance in PIXELS to the nearest wall pixel
-    // LDS layout of the step kernel (byte offsets, all 16-B aligned)
-    int32_t off_params, off_veh, off_fine, off_rank, off_path, off_coarse, off_ray, off_state, off_next, off_scan, lds_bytes, pad5;
-    int32_t eighth, scan_floats, ray_floats;   // int(n_rays / 8); floats per LDS scan = 1 + (n_rays - 2*eighth) padded to 4; padded ray table
-    float snap_eps, pad3;         // the march re-checks a landing point with the exact comparisons within this distance of a pixel boundary
-    const uint32_t* field;        // flat per-pixel OCTANT field, [height][width][2] dwords, HBM/L2.  Dword 0 serves rays whose dominant
-                                  // axis is x, dword 1 those with dominant axis y; byte q of a dword belongs to the direction quadrant
-                                  // (q&1 ? -x : +x, q&2 ? -y : +y).  A byte describes a wall-free rectangle of pixels with its corner
-                                  // at the pixel, extending AHEAD of the ray: low 7 bits = h (0 = the pixel is a wall); bit 7 clear:
-                                  // h x h square; bit 7 set: 2h along the dominant axis by h across it.
-    int32_t use_field;            // 1: the march reads `field` (flat, from L2); 0: the two-level grid staged in LDS
-    int32_t scan_full;            // 1: the LDS scan holds the whole row (flushed to HBM with coalesced 16-B stores); 0: only the driver's window
+    float snap_eps;               // the march re-checks a landing point with the exact comparisons within this distance of a pixel boundary
+    uint32_t ray_magic;           // ceil(2^32 / n_rays): pool index -> (car slot, ray) without a division
+    uint32_t plane_bytes;         // bytes per octant plane of the box field
+    int32_t contact_reach;        // chessboard reach (pixels) of the wall-contact window; `nearbits` is the wall set dilated by it
+    // step-kernel launch shape and LDS layout (byte offsets, all 16-B aligned)
+    int32_t cars_per_block, waves_per_block, eighth, win_floats;   // win_floats: floats per LDS scan row = 1 + (n_rays - 2*eighth), padded to 4
+    int32_t off_params, off_veh, off_path, off_ray, off_cars, off_frame, off_steps, off_scan, off_list, off_pool, lds_bytes, pad_l;
+    int32_t bubble_wrap, pad_b;   // custom.py:1041-1055: the four wheel softeners collide with the walls
+    const uint16_t* field;        // [FTGP_OCTANTS][height + 2][width + 2] box entries (ftgp_march.h), HBM/L2
+    const uint32_t* bits;         // [height][words_per_row] wall bitmap
+    const uint32_t* nearbits;     // [height][words_per_row] wall bitmap dilated by contact_reach (early-out of the wall contact)
     const void* veh_dev;          // VehLds image (vehicle constants + wheel loads) in HBM
     const double* path;           // [100][2]
     const double* spawn;          // [100][4] x, y, qw, qz
-    const float* ray_bx;          // body-frame ray directions (binary32)
-    const float* ray_by;
+    const float* ray_dir;         // [n_rays][2] body-frame ray directions (sin phi, -cos phi), binary32
     // state
     CarState* cars;
     float* ranges;                // [n_cars][ranges_stride]
     int64_t* steps;               // [n_envs]
     FtgpVehicle veh;              // host-side copy (kernels read the LDS image)
     double wheel_load[4];
+};
+
+// vehicle constants as staged into LDS
+struct VehLds {
+    FtgpVehicle v;
+    double wheel_load[4];
+    float cull_radius, pad;       // every part of a car that a ray can see lies within this distance of the car's origin
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -122,12 +134,14 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int m)
     hi = __shfl_xor(hi, m, FTGP_WAVE);
     return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double bcast_f64(double v, int src)
+
+// wave-uniform copy of a pointer that was read from LDS (keeps it in SGPRs: global_load with an SGPR base)
+template <typename T>
+__device__ __forceinline__ T* uniform_ptr(T* p)
 {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __shfl(lo, src, FTGP_WAVE);
-    hi = __shfl(hi, src, FTGP_WAVE);
-    return __hiloint2double(hi, lo);
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return reinterpret_cast<T*>(((uint64_t)hi << 32) | lo);
 }
 
 // Orders this wave's LDS stores before its later LDS loads (lanes exchange data through LDS without a

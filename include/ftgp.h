@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FTGP_ABI_VERSION 1
+#define FTGP_ABI_VERSION 2
 
 /* status codes */
 #define FTGP_OK              0
@@ -88,6 +88,8 @@ typedef struct FtgpVehicle {
     double lidar_ring_radius;       /* 0.03: ray j starts at centre - 0.03*dir_j (mushr.em.xml:103,115) */
     double body_z;                  /* constant ride height reported in qpos[2] */
     double box_xmin, box_xmax, box_ymin, box_ymax; /* chassis bbox, body frame, seen by other cars' rays */
+    double softener_radius;         /* bubble_wrap: wall-contact circles at the four wheel positions; 0.65 * 0.0488 = radius of
+                                       meshes/mushr_wheel.stl at the scale of mushr.em.xml:39 (softener geoms, mushr.em.xml:65-67) */
 } FtgpVehicle;
 
 typedef struct FtgpConfig {
@@ -103,6 +105,10 @@ typedef struct FtgpConfig {
                                        jitters and draws random controls exactly like the same slice of the monolithic batch */
     uint64_t seed;                  /* spawn jitter and FTGP_POLICY_RANDOM */
     double dt;                      /* 0.004 (mushr.em.xml:30) */
+    int32_t bubble_wrap;            /* option "bubble_wrap" (custom.py:970,1041-1055): the four wheel softeners (mushr.em.xml:65-67,126-129)
+                                       collide with the walls -- here: four more wall-contact circles at the wheel positions */
+    int32_t naive_flatten;          /* option "naive_flatten" (custom.py:981,1338-1339): re-projects the body quaternion onto pure yaw every
+                                       step; the planar model has no pitch / roll, so this is accepted and changes nothing */
     FtgpTrack track;
     FtgpVehicle vehicle;
 } FtgpConfig;
@@ -160,7 +166,8 @@ int ftgp_rollout(FtgpEnv *env, int policy, int n_steps);
 /* Read-backs (host buffers).  All are synchronous with respect to earlier calls on the handle. */
 
 /* float[n_cars][n_rays]; replaces data.sensordata[vehicle_state.sensors] (custom.py:1395; drive.py:81).
- * Index 0 = rear, counter-clockwise; world units; -1 = no hit; all 0 right after reset. */
+ * Index 0 = rear, counter-clockwise; world units; -1 = no hit; all 0 right after reset, and all 0 for a car that has
+ * finished (its rangefinders are switched off when it is sent to the shadow realm, custom.py:1436-1439). */
 int ftgp_get_lidar(FtgpEnv *env, float *out);
 
 /* double[n_cars][FTGP_SNAPSHOT_DOUBLES]; replaces VehicleState.snapshot (custom.py:149-160,62-76;

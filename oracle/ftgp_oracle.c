@@ -106,6 +106,7 @@ void oracle_default_vehicle(FtgpVehicle *v)
     v->lidar_x = -0.0525; v->lidar_y = 0.0; v->lidar_ring_radius = 0.03;
     v->body_z = 0.0156;
     v->box_xmin = -0.1027; v->box_xmax = 0.1034; v->box_ymin = -0.0461; v->box_ymax = 0.0472;
+    v->softener_radius = 0.65 * 0.0488;   /* mushr_wheel.stl radius at the scale of mushr.em.xml:39 */
 }
 
 /* ------------------------------------------------------------------ small math (specified polynomials) */
@@ -354,6 +355,10 @@ static void lidar_car(OracleEnv *e, int ci)
     const Car *a = &e->cars[ci];
     const int R = c->n_rays;
     float *out = e->ranges + (size_t)ci * R;
+    if (a->finished) {                                /* shadow_rangefinders: a finished car's sensors are switched off (custom.py:1436-1439) */
+        for (int j = 0; j < R; ++j) out[j] = 0.0f;
+        return;
+    }
     const double ch = 1.0 - 2.0 * (a->qz * a->qz), sh = 2.0 * (a->qw * a->qz);
     const double lcx = a->x + (ch * v->lidar_x - sh * v->lidar_y);
     const double lcy = a->y + (sh * v->lidar_x + ch * v->lidar_y);
@@ -437,59 +442,66 @@ static void progress_car(OracleEnv *e, int ci)
 /* ------------------------------------------------------------------ K1: integrate one dt */
 typedef struct Force { double fx, fy, tz; } Force;
 
-static void wall_contact(const OracleEnv *e, const Car *a, double ch, double sh, Force *f)
+/* One circle (centre = car position + (rxw, ryw), radius r) against the wall pixels: deepest penetration, ties -> first in raster order. */
+static void wall_circle(const OracleEnv *e, const Car *a, double rxw, double ryw, double r, Force *f)
 {
     const FtgpConfig *c = &e->cfg;
     const FtgpVehicle *v = &c->vehicle;
     const int W = c->track.width, H = c->track.height;
     const double sx = c->track.px_size_x, sy = c->track.px_size_y;
     const double inv_sx = 1.0 / sx, inv_sy = 1.0 / sy;
-    const double r = v->contact_radius;
     const int nx = (int)ceil(r * inv_sx), ny = (int)ceil(r * inv_sy);
     const int reach = (nx > ny ? nx : ny) + 1;
-    for (int k = 0; k < 3; ++k) {
-        double rxw = ch * v->contact_x[k], ryw = sh * v->contact_x[k];  /* body (cx, 0) rotated */
-        double px = a->x + rxw, py = a->y + ryw;
-        double u = (px - c->track.origin_x) * inv_sx, w = (c->track.origin_y - py) * inv_sy;
-        int ix = (int)floor(u), iy = (int)floor(w);
-        if (ix < 0 || ix >= W || iy < 0 || iy >= H) continue;
-        if (e->field[(size_t)iy * W + ix] > reach) continue;
-        double best_pen = 0.0, bnx = 0.0, bny = 0.0; int found = 0;
-        for (int dy = -ny; dy <= ny; ++dy) {
-            int cy = iy + dy; if (cy < 0 || cy >= H) continue;
-            for (int dx = -nx; dx <= nx; ++dx) {
-                int cx = ix + dx; if (cx < 0 || cx >= W) continue;
-                if (!wall_at(e, cx, cy)) continue;
-                /* wall cell rectangle in world coordinates */
-                double x0 = c->track.origin_x + (double)cx * sx, x1 = x0 + sx;
-                double y1 = c->track.origin_y - (double)cy * sy, y0 = y1 - sy;
-                double qx = px < x0 ? x0 : (px > x1 ? x1 : px);
-                double qy = py < y0 ? y0 : (py > y1 ? y1 : py);
-                double ex = px - qx, ey = py - qy;
-                double d2 = ex * ex + ey * ey;
-                if (d2 >= r * r) continue;
-                double d = sqrt(d2);
-                double pen = r - d;
-                if (!found || pen > best_pen) {
-                    double nxv, nyv;
-                    if (d > 0.0) { nxv = ex / d; nyv = ey / d; }
-                    else {
-                        double mx = px - (x0 + 0.5 * sx), my = py - (y0 + 0.5 * sy);
-                        double m = sqrt(mx * mx + my * my);
-                        if (m > 0.0) { nxv = mx / m; nyv = my / m; } else { nxv = 0.0; nyv = 0.0; }
-                    }
-                    best_pen = pen; bnx = nxv; bny = nyv; found = 1;
+    double px = a->x + rxw, py = a->y + ryw;
+    double u = (px - c->track.origin_x) * inv_sx, w = (c->track.origin_y - py) * inv_sy;
+    int ix = (int)floor(u), iy = (int)floor(w);
+    if (ix < 0 || ix >= W || iy < 0 || iy >= H) return;
+    if (e->field[(size_t)iy * W + ix] > reach) return;
+    double best_pen = 0.0, bnx = 0.0, bny = 0.0; int found = 0;
+    for (int dy = -ny; dy <= ny; ++dy) {
+        int cy = iy + dy; if (cy < 0 || cy >= H) continue;
+        for (int dx = -nx; dx <= nx; ++dx) {
+            int cx = ix + dx; if (cx < 0 || cx >= W) continue;
+            if (!wall_at(e, cx, cy)) continue;
+            /* wall cell rectangle in world coordinates */
+            double x0 = c->track.origin_x + (double)cx * sx, x1 = x0 + sx;
+            double y1 = c->track.origin_y - (double)cy * sy, y0 = y1 - sy;
+            double qx = px < x0 ? x0 : (px > x1 ? x1 : px);
+            double qy = py < y0 ? y0 : (py > y1 ? y1 : py);
+            double ex = px - qx, ey = py - qy;
+            double d2 = ex * ex + ey * ey;
+            if (d2 >= r * r) continue;
+            double d = sqrt(d2);
+            double pen = r - d;
+            if (!found || pen > best_pen) {
+                double nxv, nyv;
+                if (d > 0.0) { nxv = ex / d; nyv = ey / d; }
+                else {
+                    double mx = px - (x0 + 0.5 * sx), my = py - (y0 + 0.5 * sy);
+                    double m = sqrt(mx * mx + my * my);
+                    if (m > 0.0) { nxv = mx / m; nyv = my / m; } else { nxv = 0.0; nyv = 0.0; }
                 }
+                best_pen = pen; bnx = nxv; bny = nyv; found = 1;
             }
         }
-        if (!found) continue;
-        double vcx = a->vx - a->wz * ryw, vcy = a->vy + a->wz * rxw;
-        double vn = vcx * bnx + vcy * bny;
-        double mag = v->contact_stiffness * best_pen - v->contact_damping * vn;
-        if (mag <= 0.0) continue;
-        double fx = mag * bnx, fy = mag * bny;
-        f->fx += fx; f->fy += fy; f->tz += rxw * fy - ryw * fx;
     }
+    if (!found) return;
+    double vcx = a->vx - a->wz * ryw, vcy = a->vy + a->wz * rxw;
+    double vn = vcx * bnx + vcy * bny;
+    double mag = v->contact_stiffness * best_pen - v->contact_damping * vn;
+    if (mag <= 0.0) return;
+    double fx = mag * bnx, fy = mag * bny;
+    f->fx += fx; f->fy += fy; f->tz += rxw * fy - ryw * fx;
+}
+
+static void wall_contact(const OracleEnv *e, const Car *a, double ch, double sh, Force *f)
+{
+    const FtgpVehicle *v = &e->cfg.vehicle;
+    for (int k = 0; k < 3; ++k)                                           /* chassis circles, body (cx, 0) rotated */
+        wall_circle(e, a, ch * v->contact_x[k], sh * v->contact_x[k], v->contact_radius, f);
+    if (e->cfg.bubble_wrap)                                               /* wheel softeners (custom.py:1041-1055; mushr.em.xml:65-67,126-129) */
+        for (int k = 0; k < 4; ++k)
+            wall_circle(e, a, ch * v->wheel_x[k] - sh * v->wheel_y[k], sh * v->wheel_x[k] + ch * v->wheel_y[k], v->softener_radius, f);
 }
 
 static void car_contact(const OracleEnv *e, int ci, double ch, double sh, Force *f)

@@ -314,22 +314,27 @@ def test_finished_cars_become_ghosts(product, oracle):
         np.testing.assert_array_equal(r[0], r[1])
 
 
-def test_both_acceleration_structures_return_the_same_bits(product, oracle, monkeypatch):
-    """The LiDAR specification is independent of the skipping structure: flat per-pixel field (L2) == two-level LDS grid == oracle."""
+def test_workgroup_shape_does_not_change_a_bit(product, oracle, monkeypatch):
+    """Which wave / lane marches which ray, how many cars share a workgroup and its ray pool, and how many waves sweep it
+    are scheduling only: every shape must return the oracle's bits (single- and multi-car envs)."""
     t = load_track("inkscape")
-    kw = dict(n_envs=64, n_rays=1080, spawn_mode=1, seed=21)
-    monkeypatch.setenv("FTGP_FIELD", "global"); a = capi.Env(product, t, **kw)
-    monkeypatch.setenv("FTGP_FIELD", "lds");    b = capi.Env(product, t, **kw)
-    monkeypatch.delenv("FTGP_FIELD")
-    o = capi.Env(oracle, t, **kw); oracle.dll.oracle_set_threads(o.h, 8)
-    with a, b, o:
-        assert a.kernel_name() != b.kernel_name()
-        for e in (a, b, o):
-            e.rollout("fast", 300)
-        np.testing.assert_array_equal(a.lidar(), b.lidar())
-        np.testing.assert_array_equal(a.pose(), b.pose())
-        np.testing.assert_array_equal(a.progress(), b.progress())
-        assert_same_state(a, o); assert_same_state(b, o)
+    for cars, shapes in ((1, ((16, 16), (1, 16), (5, 3), (16, 1))), (3, ((15, 16), (3, 7), (6, 2)))):
+        kw = dict(n_envs=40 // cars, cars_per_env=cars, n_rays=1080, spawn_mode=1 if cars == 1 else 0, seed=21, lap_target=2)
+        envs = []
+        for cpb, wpb in shapes:
+            monkeypatch.setenv("FTGP_CARS_PER_BLOCK", str(cpb)); monkeypatch.setenv("FTGP_WAVES_PER_BLOCK", str(wpb))
+            envs.append(capi.Env(product, t, **kw))
+        monkeypatch.delenv("FTGP_CARS_PER_BLOCK"); monkeypatch.delenv("FTGP_WAVES_PER_BLOCK")
+        o = capi.Env(oracle, t, **kw); oracle.dll.oracle_set_threads(o.h, 8)
+        for e in envs + [o]:
+            e.rollout("fast", 250)
+        for e in envs:
+            np.testing.assert_array_equal(e.lidar(), envs[0].lidar())
+            np.testing.assert_array_equal(e.pose(), envs[0].pose())
+            np.testing.assert_array_equal(e.progress(), envs[0].progress())
+            assert_same_state(e, o)
+        for e in envs + [o]:
+            e.close()
 
 
 def test_config2_and_config5_full_size_properties(product, oracle):

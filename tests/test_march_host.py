@@ -1,4 +1,4 @@
-"""The SHIPPED march_grid() / build_grid() / grid_wall() compiled for the host and checked against the plain-DDA
+"""The SHIPPED march (ftgp_march.h: ftgp_ray_init/step/fix/commit), box search (ftgp_box_entry) and host tables compiled for the host and checked against the plain-DDA
 specification on millions of rays (random + rays from pixel corners + axis-aligned / diagonal directions)."""
 import os
 import shutil

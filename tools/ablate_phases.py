@@ -6,7 +6,7 @@ from ft_grandprix_amd.track import load_track
 t = load_track("track")
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 libs = {"full": capi.product_library_path()}
-for tag in ("K1", "K2", "K3"):
+for tag in ("K1", "K2"):
     libs["no" + tag] = os.path.join(root, "gpurun_out", f"libftgp_no{tag}.so")
 for n_rays, policy in ((1080, "fast"), (1080, "lobotomy"), (8, "lobotomy")):
     for name, path in libs.items():

@@ -1,4 +1,4 @@
-// Host harness: runs the SHIPPED march_grid() and build_grid() on the CPU against a plain DDA (the specification)
+// Host harness: runs the SHIPPED march (ftgp_march.h), box search and build_tables() on the CPU against a plain DDA (the specification)
 // over random rays.  Build: hipcc --offload-arch=gfx950 -O2 -ffp-contract=off -std=c++17 -x hip tools/march_check.cpp -o /tmp/march_check
 // Input: raw track dump written by tests (int32 W, H, wpr; then uint32 bits[H*wpr]).
 #include "../ft_grandprix_amd/csrc/ftgp_api.hip"
@@ -34,21 +34,21 @@ int main(int argc, char** argv)
     const unsigned seed = argc > 3 ? (unsigned)atoi(argv[3]) : 1;
     const double scale = argc > 4 ? atof(argv[4]) : 40.0;     // pixels per world unit (1/px_size)
     FtgpTrack t{}; t.width = hdr[0]; t.height = hdr[1]; t.words_per_row = hdr[2]; t.bits = bits.data();
-    HostGrid g; build_grid(t, g);
-    DeviceParams P{}; P.width = t.width; P.height = t.height; P.nbx = g.nbx; P.nby = g.nby; P.nwpr = g.nwpr; P.n_fine = g.n_fine;
-    P.snap_eps = 1.0f / 512.0f;
-    P.n_rays = 8; P.eighth = 1; P.scan_floats = 8; P.ray_floats = 8;
-    lds_layout(P, 1);
-    std::vector<unsigned char> img((size_t)P.lds_bytes, 0);
-    memcpy(img.data() + P.off_fine, g.fine.data(), g.fine.size());
-    memcpy(img.data() + P.off_rank, g.rank.data(), g.rank.size() * sizeof(uint2));
-    memcpy(img.data() + P.off_coarse, g.coarse.data(), g.coarse.size());
-    LdsView L{}; L.fine = img.data() + P.off_fine; L.rank = reinterpret_cast<const uint2*>(img.data() + P.off_rank); L.coarse = img.data() + P.off_coarse;
+    // the shipped host tables + the shipped per-cell box search (ftgp_box_entry, the body of ftgp_box_field_kernel) on the CPU
+    HostTables g; build_tables(t, 3, g);
+    const int W = t.width, H = t.height;
+    const size_t cells = (size_t)(W + 2) * (H + 2);
+    std::vector<uint16_t> field(cells * FTGP_OCTANTS, (uint16_t)FTGP_FIELD_OUT);
     long gw_bad = 0;
-    for (int y = 0; y < t.height; ++y)
-        for (int x = 0; x < t.width; ++x)
-            if (grid_wall(P, L, x, y) != wall_at(t, x, y)) { if (gw_bad < 5) printf("grid_wall mismatch at %d %d: %d vs %d\n", x, y, (int)grid_wall(P, L, x, y), (int)wall_at(t, x, y)); ++gw_bad; }
+    for (int oct = 0; oct < FTGP_OCTANTS; ++oct)
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) {
+                const uint32_t e = ftgp_box_entry(g.ksq.data(), g.runx.data(), g.runy.data(), W, H, x, y, oct);
+                field[(size_t)oct * cells + (size_t)(y + 1) * (W + 2) + (x + 1)] = (uint16_t)e;
+                if ((e == 0) != wall_at(t, x, y) || (e != 0 && (e & 255u) == 0)) ++gw_bad;      // 0 <=> wall; a free cell never carries kx = 0
+            }
     printf("grid_wall: %ld mismatching pixels\n", gw_bad);
+    const float eps = 1.0f / 512.0f;
     std::mt19937_64 rng(seed);
     std::uniform_real_distribution<double> ux(0, t.width), uy(0, t.height), ua(0, 2 * M_PI), u01(0, 1);
     long bad = 0, hits = 0;
@@ -63,7 +63,7 @@ int main(int argc, char** argv)
         float du = (float)(cos(a) * scale), dv = (float)(sin(a) * scale);
         if (kind == 3 || kind == 4) { if (fabsf(du) < 1e-3f) du = 0.0f; if (fabsf(dv) < 1e-3f) dv = 0.0f; }
         if (kind == 2 && (i & 8)) { du = (float)(int)(du); dv = (float)(int)dv; if (du == 0 && dv == 0) du = 1; }
-        const float a_ = march_grid(P, img.data(), pu, pv, du, dv), b_ = plain(t, pu, pv, du, dv);
+        const float a_ = ftgp_march_one(field.data(), W, H, eps, pu, pv, du, dv), b_ = plain(t, pu, pv, du, dv);
         hits += b_ >= 0;
         if (memcmp(&a_, &b_, 4) != 0) {
             if (bad < 10) printf("MISMATCH kind %d pu %.9g pv %.9g du %.9g dv %.9g : grid %.9g plain %.9g\n", kind, pu, pv, du, dv, a_, b_);

@@ -1,0 +1,18 @@
+#!/usr/bin/env python3
+"""Kernel time of the three throughput configurations (BASELINE.json configs[2], [1], [4]): quick_perf.py [lib.so ...]"""
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from ft_grandprix_amd import capi
+from ft_grandprix_amd.track import load_track
+libs = sys.argv[1:] or [capi.product_library_path()]
+cases = (("track", "fast", 4096, 1, 300), ("circle", "nidc", 1024, 1, 300), ("track", "fast", 4096, 4, 100), ("track", "random", 4096, 1, 300))
+for path in libs:
+    lib = capi.CLib(path, "ftgp_")
+    out = []
+    for name, policy, envs, cars, steps in cases:
+        with capi.Env(lib, load_track(name), n_envs=envs, cars_per_env=cars, n_rays=1080, spawn_mode=1 if cars == 1 else 0, seed=1234) as e:
+            e.rollout(policy, 100); e.last_kernel_ms(); best = 1e9
+            for _ in range(3):
+                e.rollout(policy, steps); best = min(best, e.last_kernel_ms())
+        out.append(f"{name}/{policy}/{envs}x{cars}: {best * 1e3 / steps:7.2f} us/step = {envs * steps / best / 1e3:6.2f} M env-steps/s")
+    print(os.path.basename(path), " | ".join(out), flush=True)

@@ -1,0 +1,147 @@
+// CPU model of the LiDAR sweep scheduling (tools only): runs the SHIPPED march (ftgp_march.h) for real poses and counts what
+// the wave-level schedule of lidar_pool() costs -- wave-iterations, refills, fix branches -- per car-step, for a given
+// workgroup shape and refill threshold.  Waves of a workgroup take turns round by round (the real order is timing
+// dependent; the totals barely move).
+//   build: g++ -O2 -std=c++17 -I. tools/sweep_model.cpp -o /tmp/sweep_model
+//   run:   /tmp/sweep_model track.raw poses.bin n_rays cars_per_block waves_per_block refill [eps_log2]
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <vector>
+#include "../include/ftgp.h"
+#include "../ft_grandprix_amd/csrc/ftgp_march.h"
+
+struct Tables { std::vector<uint8_t> wall, ksq; std::vector<uint16_t> runx, runy; };
+static void build(const std::vector<uint32_t>& bits, int W, int H, int wpr, Tables& g)
+{
+    g.wall.assign((size_t)W * H, 0);
+    for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) if ((bits[(size_t)y * wpr + (x >> 5)] >> (x & 31)) & 1u) g.wall[(size_t)y * W + x] = 1;
+    const size_t plane = (size_t)W * H;
+    g.ksq.assign(4 * plane, 0);
+    std::vector<int> prev((size_t)W + 2), cur((size_t)W + 2);
+    for (int q = 0; q < 4; ++q) {
+        const int sx = (q & 1) ? -1 : 1, sy = (q & 2) ? -1 : 1;
+        std::fill(prev.begin(), prev.end(), 1 << 20);
+        for (int yy = 0; yy < H; ++yy) {
+            const int y = sy > 0 ? H - 1 - yy : yy;
+            std::fill(cur.begin(), cur.end(), 1 << 20);
+            for (int xx = 0; xx < W; ++xx) {
+                const int x = sx > 0 ? W - 1 - xx : xx;
+                int v = 0;
+                if (!g.wall[(size_t)y * W + x]) v = 1 + std::min(std::min(cur[(size_t)(x + sx + 1)], prev[(size_t)(x + 1)]), prev[(size_t)(x + sx + 1)]);
+                cur[(size_t)(x + 1)] = v;
+                g.ksq[(size_t)q * plane + (size_t)y * W + x] = (uint8_t)std::min(255, v);
+            }
+            std::swap(prev, cur);
+        }
+    }
+    g.runx.assign(2 * plane, 0); g.runy.assign(2 * plane, 0);
+    for (int y = 0; y < H; ++y) {
+        int r = 65535;
+        for (int x = W - 1; x >= 0; --x) { r = g.wall[(size_t)y * W + x] ? 0 : std::min(65535, r + 1); g.runx[(size_t)y * W + x] = (uint16_t)r; }
+        r = 65535;
+        for (int x = 0; x < W; ++x) { r = g.wall[(size_t)y * W + x] ? 0 : std::min(65535, r + 1); g.runx[plane + (size_t)y * W + x] = (uint16_t)r; }
+    }
+    for (int x = 0; x < W; ++x) {
+        int r = 65535;
+        for (int y = H - 1; y >= 0; --y) { r = g.wall[(size_t)y * W + x] ? 0 : std::min(65535, r + 1); g.runy[(size_t)y * W + x] = (uint16_t)r; }
+        r = 65535;
+        for (int y = 0; y < H; ++y) { r = g.wall[(size_t)y * W + x] ? 0 : std::min(65535, r + 1); g.runy[plane + (size_t)y * W + x] = (uint16_t)r; }
+    }
+}
+
+#ifndef BOX_ENTRY
+#define BOX_ENTRY ftgp_box_entry
+#endif
+
+int main(int argc, char** argv)
+{
+    if (argc < 7) { fprintf(stderr, "usage\n"); return 2; }
+    FILE* f = fopen(argv[1], "rb"); int32_t hdr[3]; if (!f || fread(hdr, 4, 3, f) != 3) return 2;
+    const int W = hdr[0], H = hdr[1], wpr = hdr[2];
+    std::vector<uint32_t> bits((size_t)H * wpr); if (fread(bits.data(), 4, bits.size(), f) != bits.size()) return 2; fclose(f);
+    f = fopen(argv[2], "rb"); if (!f) return 2;
+    double ph[6]; if (fread(ph, 8, 6, f) != 6) return 2;      // n_cars, px_size_x, px_size_y, origin_x, origin_y, reserved
+    const int n_cars = (int)ph[0];
+    std::vector<double> pose((size_t)n_cars * 4); if (fread(pose.data(), 8, pose.size(), f) != pose.size()) return 2; fclose(f);
+    const int R = atoi(argv[3]), cpb = atoi(argv[4]), wpb = atoi(argv[5]), refill = atoi(argv[6]);
+    const float eps = ldexpf(1.0f, -(argc > 7 ? atoi(argv[7]) : 9));
+    Tables g; build(bits, W, H, wpr, g);
+    const size_t cells = (size_t)(W + 2) * (H + 2);
+    std::vector<uint16_t> field(cells * FTGP_OCTANTS, (uint16_t)FTGP_FIELD_OUT);
+    for (int oct = 0; oct < FTGP_OCTANTS; ++oct) for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x)
+        field[(size_t)oct * cells + (size_t)(y + 1) * (W + 2) + (x + 1)] = (uint16_t)BOX_ENTRY(g.ksq.data(), g.runx.data(), g.runy.data(), W, H, x, y, oct);
+    const int fstride = W + 2; const uint32_t plane_bytes = 2u * (uint32_t)fstride * (uint32_t)(H + 2);
+    std::vector<float> bx(R), by(R);
+    for (int j = 0; j < R; ++j) { const double phi = ((360.0 / R) * j - 90.0) * (M_PI / 180.0); bx[j] = (float)sin(phi); by[j] = (float)(-cos(phi)); }
+    const float isx = (float)(1.0 / ph[1]), isy = (float)(1.0 / ph[2]), r0 = 0.03f;
+    long wave_iters = 0, refills = 0, fixes = 0, lane_iters = 0, rays = 0, max_wave_iters_sum = 0, lines = 0;
+    struct Lane { FtgpRay r; int g; bool done; };
+    for (int c0 = 0; c0 < n_cars; c0 += cpb) {
+        const int nc = std::min(cpb, n_cars - c0), total = nc * R;
+        int pool = 0;
+        std::vector<std::vector<Lane>> wv(wpb, std::vector<Lane>(64));
+        std::vector<int> witers(wpb, 0); std::vector<char> empty(wpb, 0), fin(wpb, 0);
+        for (auto& w : wv) for (auto& l : w) { ftgp_ray_park(l.r, -1.0f); l.g = -1; l.done = true; }
+        int alive = wpb;
+        while (alive > 0) {
+            for (int w = 0; w < wpb; ++w) {
+                if (fin[w]) continue;
+                auto& L = wv[w];
+                for (auto& l : L) if (l.done && l.g >= 0) { l.g = -1; ++rays; }
+                if (!empty[w]) {
+                    int nfree = 0; for (auto& l : L) nfree += l.done;
+                    const int base = pool; pool += nfree; ++refills;
+                    int rank = 0;
+                    for (auto& l : L) if (l.done) {
+                        const int mine = base + rank++;
+                        if (mine < total) {
+                            l.g = mine; const int c = mine / R, j = mine % R;
+                            const double* p = &pose[(size_t)(c0 + c) * 4];
+                            const double ch = 1.0 - 2.0 * (p[3] * p[3]), sh = 2.0 * (p[2] * p[3]);
+                            const double lcx = p[0] + (ch * -0.0525 - sh * 0.0), lcy = p[1] + (sh * -0.0525 + ch * 0.0);
+                            const float u0 = (float)((lcx - ph[3]) * (1.0 / ph[1])), v0 = (float)((ph[4] - lcy) * (1.0 / ph[2]));
+                            const float chf = (float)ch, shf = (float)sh;
+                            const float dxw = fmaf(chf, bx[j], -(shf * by[j])), dyw = fmaf(shf, bx[j], chf * by[j]);
+                            const float du = dxw * isx, dv = -(dyw * isy);
+                            ftgp_ray_init(l.r, fmaf(du, -r0, u0), fmaf(dv, -r0, v0), du, dv, W, H, fstride, plane_bytes);
+                            l.done = false;
+                        }
+                    }
+                    empty[w] = base + nfree >= total;
+                }
+                bool any = false; for (auto& l : L) any |= l.g >= 0;
+                if (!any) { fin[w] = 1; --alive; continue; }
+                const int want = empty[w] ? 64 : refill;
+                for (int guard = 0; guard < 32768; ++guard) {
+                    bool anynear = false; int ndone = 0;
+                    std::vector<int> lineset;
+                    for (auto& l : L) {
+                        const int off = ftgp_ray_offset(l.r, fstride);
+                        lineset.push_back(off >> 7);
+                        const uint32_t wq = field[off >> 1];
+                        FtgpStep st; const bool near = ftgp_ray_step(l.r, wq, eps, st);
+                        anynear |= near;
+                        const int t = near ? ftgp_ray_fix(l.r, st) : st.t;
+                        ftgp_ray_commit(l.r, st, t);
+                        if (!l.done || l.g >= 0) lane_iters += !l.done;
+                        l.done = st.done; ndone += st.done;
+                    }
+                    std::sort(lineset.begin(), lineset.end()); lines += std::unique(lineset.begin(), lineset.end()) - lineset.begin();
+                    ++wave_iters; ++witers[w]; fixes += anynear;
+                    if (ndone >= want) break;
+                }
+            }
+        }
+        max_wave_iters_sum += *std::max_element(witers.begin(), witers.end());
+    }
+    const double nsteps = (double)n_cars;
+    printf("R %d cpb %d wpb %d refill %d eps 2^-%d: per car-step: wave-iters %.1f  refills %.1f  fix-branches %.1f  useful lane-iters %.0f (util %.2f)  iters/ray %.2f  "
+           "max wave-iters per WG %.1f  128B-lines per wave-iter %.1f\n",
+           R, cpb, wpb, refill, (int)-log2f(eps), wave_iters / nsteps, refills / nsteps, fixes / nsteps, lane_iters / nsteps, lane_iters / (64.0 * wave_iters),
+           (double)lane_iters / rays, (double)max_wave_iters_sum / ((n_cars + cpb - 1) / cpb), (double)lines / wave_iters);
+    return 0;
+}
