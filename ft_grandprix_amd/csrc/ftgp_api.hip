@@ -110,12 +110,11 @@ void chessboard_dt(const std::vector<uint8_t>& occ, int W, int H, std::vector<in
         for (int x = 0; x < W; ++x) out[(size_t)y * W + x] = at(x, y);
 }
 
-// Host-side inputs of the octant box field (the boxes themselves are searched on the GPU, ftgp_box_field_kernel) and the
+// Host-side inputs of the sector box field (the boxes themselves are searched on the GPU, ftgp_box_field_kernel) and the
 // bitmaps of the wall contact.
 struct HostTables {
     std::vector<uint8_t> wall;        // [H][W] 1 = wall
-    std::vector<uint8_t> ksq;         // [4][H][W] largest wall-free forward square per quadrant (clamp 255)
-    std::vector<uint16_t> runx, runy; // [2][H][W] wall-free run lengths along +x / -x and +y / -y (65535 = beyond the image)
+    std::vector<uint16_t> runx, runy; // [2][H][W] wall-free run lengths along +x / -x and +y / -y (0 on walls, 65535 = beyond the image)
     std::vector<uint32_t> bits, nearbits;   // [H][wpr], padding bits clear
 };
 
@@ -134,29 +133,7 @@ void build_tables(const FtgpTrack& t, int reach, HostTables& g)
     for (int y = 0; y < H; ++y)
         for (int x = 0; x < W; ++x)
             if (dpx[(size_t)y * W + x] <= reach) g.nearbits[(size_t)y * wpr + (x >> 5)] |= 1u << (x & 31);
-    //   ksq[q](x, y) = side of the largest wall-free square of pixels with its corner at (x, y), extending towards
-    //   (q&1 ? -x : +x, q&2 ? -y : +y); pixels beyond the image count as free; 0 on walls.  Classic largest-square recurrence.
     const size_t plane = (size_t)W * H;
-    g.ksq.assign(4 * plane, 0);
-    {
-        std::vector<int> prev((size_t)W + 2), cur((size_t)W + 2);
-        for (int q = 0; q < 4; ++q) {
-            const int sx = (q & 1) ? -1 : 1, sy = (q & 2) ? -1 : 1;
-            std::fill(prev.begin(), prev.end(), 1 << 20);
-            for (int yy = 0; yy < H; ++yy) {
-                const int y = sy > 0 ? H - 1 - yy : yy;          // start at the far edge of the direction of travel
-                std::fill(cur.begin(), cur.end(), 1 << 20);
-                for (int xx = 0; xx < W; ++xx) {
-                    const int x = sx > 0 ? W - 1 - xx : xx;
-                    int v = 0;
-                    if (!g.wall[(size_t)y * W + x]) v = 1 + std::min(std::min(cur[(size_t)(x + sx + 1)], prev[(size_t)(x + 1)]), prev[(size_t)(x + sx + 1)]);
-                    cur[(size_t)(x + 1)] = v;
-                    g.ksq[(size_t)q * plane + (size_t)y * W + x] = (uint8_t)std::min(255, v);
-                }
-                std::swap(prev, cur);
-            }
-        }
-    }
     g.runx.assign(2 * plane, 0); g.runy.assign(2 * plane, 0);
     for (int y = 0; y < H; ++y) {
         int r = 65535;
@@ -183,9 +160,9 @@ int lds_layout(DeviceParams& P, int cpb, int wpb)
     P.off_path = o;   o += pad16(sizeof(double) * 2 * FTGP_PATH_POINTS);
     P.off_ray = o;    o += pad16(sizeof(float) * 2 * (size_t)P.n_rays);
     P.off_cars = o;   o += cpb * (int)sizeof(CarCore);
-    P.off_frame = o;  o += cpb * (int)sizeof(LidarFrame);
+    P.off_frame = o;  o += 2 * cpb * (int)sizeof(LidarFrame);      // double-buffered by step parity
     P.off_steps = o;  o += pad16((size_t)cpb * sizeof(int64_t));
-    P.off_scan = o;   o += cpb * P.win_floats * (int)sizeof(float);
+    P.off_scan = o;   o += 2 * cpb * P.win_floats * (int)sizeof(float);   // double-buffered by step parity
     P.off_list = o;   o += wpb * FTGP_WAVE * (int)sizeof(int);
     P.off_pool = o;   o += 16;
     P.lds_bytes = o;
@@ -412,21 +389,19 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
         spawn[4 * p + 2] = cos(ang / 2); spawn[4 * p + 3] = sin(ang / 2);
     }
 
-    {   // octant box field: upload the squares and run lengths, search the boxes on the device
+    {   // sector box field: upload the run lengths, search the boxes on the device
         const size_t plane = (size_t)t.width * t.height;
-        const size_t cells = (size_t)(t.width + 2) * (t.height + 2) * FTGP_OCTANTS;
-        uint8_t* d_ksq = nullptr; uint16_t* d_runx = nullptr; uint16_t* d_runy = nullptr;
+        const size_t cells = (size_t)(t.width + 2) * (t.height + 2) * FTGP_SECTORS;
+        uint16_t* d_runx = nullptr; uint16_t* d_runy = nullptr;
         CREATE_TRY(hipMalloc(&e->d_field, cells * sizeof(uint16_t)));
-        CREATE_TRY(hipMalloc(&d_ksq, 4 * plane));
         CREATE_TRY(hipMalloc(&d_runx, 2 * plane * sizeof(uint16_t)));
         CREATE_TRY(hipMalloc(&d_runy, 2 * plane * sizeof(uint16_t)));
-        CREATE_TRY(hipMemcpy(d_ksq, tab.ksq.data(), 4 * plane, hipMemcpyHostToDevice));
         CREATE_TRY(hipMemcpy(d_runx, tab.runx.data(), 2 * plane * sizeof(uint16_t), hipMemcpyHostToDevice));
         CREATE_TRY(hipMemcpy(d_runy, tab.runy.data(), 2 * plane * sizeof(uint16_t), hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(ftgp_box_field_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, e->stream, d_ksq, d_runx, d_runy, t.width, t.height, e->d_field);
+        hipLaunchKernelGGL(ftgp_box_field_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, e->stream, d_runx, d_runy, t.width, t.height, e->d_field);
         CREATE_TRY(hipGetLastError());
         CREATE_TRY(hipStreamSynchronize(e->stream));
-        (void)hipFree(d_ksq); (void)hipFree(d_runx); (void)hipFree(d_runy);
+        (void)hipFree(d_runx); (void)hipFree(d_runy);
         P.field = e->d_field;
     }
     {
@@ -749,6 +724,16 @@ int ftgp_last_kernel_ms(FtgpEnv* e, float* ms)
     HIP_TRY(hipEventElapsedTime(ms, e->ev_start, e->ev_stop));
     return 0;
 }
+
+#ifdef FTGP_STAMPS
+// diagnostic build only: read and clear the phase stamps
+int ftgp_debug_stamps(unsigned long long* out)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ftgp_stamps), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    unsigned long long z[16] = { 0 };
+    return hipMemcpyToSymbol(HIP_SYMBOL(ftgp_stamps), z, sizeof z) == hipSuccess ? 0 : -1;
+}
+#endif
 
 const char* ftgp_kernel_name(FtgpEnv* e)
 {

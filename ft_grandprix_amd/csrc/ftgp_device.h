@@ -50,13 +50,13 @@ struct DeviceParams {
     float inv_px_x_f, inv_px_y_f;
     float snap_eps;               // the march re-checks a landing point with the exact comparisons within this distance of a pixel boundary
     uint32_t ray_magic;           // ceil(2^32 / n_rays): pool index -> (car slot, ray) without a division
-    uint32_t plane_bytes;         // bytes per octant plane of the box field
+    uint32_t plane_bytes;         // bytes per sector plane of the box field
     int32_t contact_reach;        // chessboard reach (pixels) of the wall-contact window; `nearbits` is the wall set dilated by it
     // step-kernel launch shape and LDS layout (byte offsets, all 16-B aligned)
     int32_t cars_per_block, waves_per_block, eighth, win_floats;   // win_floats: floats per LDS scan row = 1 + (n_rays - 2*eighth), padded to 4
     int32_t off_params, off_veh, off_path, off_ray, off_cars, off_frame, off_steps, off_scan, off_list, off_pool, lds_bytes, pad_l;
     int32_t bubble_wrap, pad_b;   // custom.py:1041-1055: the four wheel softeners collide with the walls
-    const uint16_t* field;        // [FTGP_OCTANTS][height + 2][width + 2] box entries (ftgp_march.h), HBM/L2
+    const uint16_t* field;        // [FTGP_SECTORS][height + 2][width + 2] box entries (ftgp_march.h), HBM/L2
     const uint32_t* bits;         // [height][words_per_row] wall bitmap
     const uint32_t* nearbits;     // [height][words_per_row] wall bitmap dilated by contact_reach (early-out of the wall contact)
     const void* veh_dev;          // VehLds image (vehicle constants + wheel loads) in HBM
@@ -134,6 +134,10 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int m)
     hi = __shfl_xor(hi, m, FTGP_WAVE);
     return __hiloint2double(hi, lo);
 }
+
+// wave-uniform values pinned in SGPRs (values read from LDS arrive in VGPRs even when every lane reads the same address)
+__device__ __forceinline__ int sgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float sgpr(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 
 // wave-uniform copy of a pointer that was read from LDS (keeps it in SGPRs: global_load with an SGPR base)
 template <typename T>

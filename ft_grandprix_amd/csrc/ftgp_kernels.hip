@@ -9,13 +9,13 @@
 //       The sweep reads the LiDAR frames, never the live state, so K1 of step t runs beside K2 of step t (K1 needs the
 //       controls of step t and those depend only on the scan of step t-1).
 //       Staged into LDS once per launch with coalesced 16-B loads: parameter block, vehicle constants, centre-line, ray table,
-//       the cars' state records and the scan window the driver reads.  The march reads the octant box field from L2
+//       the cars' state records and the scan window the driver reads.  The march reads the sector box field from L2
 //       (ftgp_march.h); ranges go to HBM as 4-byte stores that merge in L2.
 //   ftgp_policy_kernel    K5 alone (ftgp_policy_eval).
 //   ftgp_reset_kernel     K4 reset / spawn (+ K3 at the spawn pose), one car per lane.
 //   ftgp_progress_kernel  K3 alone (after ftgp_set_pose), one car per lane.
 //   ftgp_fakelidar_kernel raycast.fakelidar restated, one ray per lane.
-//   ftgp_box_field_kernel the octant box field at create.
+//   ftgp_box_field_kernel the sector box field at create.
 //   ftgp_metrics_kernel   per-GPU metrics record.
 //
 // Reference behaviour restated by each block is cited inline (paths relative to the reference repo).
@@ -28,25 +28,40 @@ struct Lds {
     const double* path;
     const float2* ray;        // body-frame ray directions
     CarCore* cars;
-    LidarFrame* frame;
+    LidarFrame* frame;        // [2][cars_per_block], double-buffered by step parity
     int64_t* steps;
-    float* scan;              // [cars_per_block][win_floats]: ranges[0] | ranges[eighth : n - eighth]
+    float* scan;              // [2][cars_per_block][win_floats]: ranges[0] | ranges[eighth : n - eighth], double-buffered by step parity
     int* list;                // [waves_per_block][64] driver scratch
-    int* pool;                // next ray of the sweep
+    int* pool;                // [2] next ray of the sweep, [2] drivers finished -- both double-buffered by step parity
 };
 
-__device__ __forceinline__ Lds lds_view(const DeviceParams& P, unsigned char* lds)
+// A wave-uniform value the optimiser cannot see through.  The step loop rebuilds its LDS pointers from such offsets every
+// step, so loads of constants (vehicle parameters, centre-line, ...) are never hoisted out of the loop -- hoisted, they
+// would stay live across the sweep and end up in scratch memory under the 64-VGPR budget.
+__device__ __forceinline__ int opaque(int v) { asm volatile("" : "+s"(v)); return v; }
+
+struct LdsOffsets { int params, veh, path, ray, cars, frame, steps, scan, list, pool; };
+
+__device__ __forceinline__ LdsOffsets lds_offsets(const DeviceParams& P)
+{
+    LdsOffsets o;
+    o.params = sgpr(P.off_params); o.veh = sgpr(P.off_veh); o.path = sgpr(P.off_path); o.ray = sgpr(P.off_ray); o.cars = sgpr(P.off_cars);
+    o.frame = sgpr(P.off_frame); o.steps = sgpr(P.off_steps); o.scan = sgpr(P.off_scan); o.list = sgpr(P.off_list); o.pool = sgpr(P.off_pool);
+    return o;
+}
+
+__device__ __forceinline__ Lds lds_view(const LdsOffsets& o, unsigned char* lds)
 {
     Lds L;
-    L.veh = reinterpret_cast<const VehLds*>(lds + P.off_veh);
-    L.path = reinterpret_cast<const double*>(lds + P.off_path);
-    L.ray = reinterpret_cast<const float2*>(lds + P.off_ray);
-    L.cars = reinterpret_cast<CarCore*>(lds + P.off_cars);
-    L.frame = reinterpret_cast<LidarFrame*>(lds + P.off_frame);
-    L.steps = reinterpret_cast<int64_t*>(lds + P.off_steps);
-    L.scan = reinterpret_cast<float*>(lds + P.off_scan);
-    L.list = reinterpret_cast<int*>(lds + P.off_list);
-    L.pool = reinterpret_cast<int*>(lds + P.off_pool);
+    L.veh = reinterpret_cast<const VehLds*>(lds + opaque(o.veh));
+    L.path = reinterpret_cast<const double*>(lds + opaque(o.path));
+    L.ray = reinterpret_cast<const float2*>(lds + opaque(o.ray));
+    L.cars = reinterpret_cast<CarCore*>(lds + opaque(o.cars));
+    L.frame = reinterpret_cast<LidarFrame*>(lds + opaque(o.frame));
+    L.steps = reinterpret_cast<int64_t*>(lds + opaque(o.steps));
+    L.scan = reinterpret_cast<float*>(lds + opaque(o.scan));
+    L.list = reinterpret_cast<int*>(lds + opaque(o.list));
+    L.pool = reinterpret_cast<int*>(lds + opaque(o.pool));
     return L;
 }
 
@@ -104,15 +119,14 @@ __device__ __forceinline__ float ray_vs_car(const FtgpVehicle& v, const LidarFra
 // of the wave are finished, their ranges are stored and they take the next rays of the pool together (one LDS atomic
 // per refill, rank among the free lanes via ballot/popcount).  Which lane marches which ray has no influence on any result.
 #ifndef FTGP_REFILL
-#define FTGP_REFILL 32
+#define FTGP_REFILL 48
 #endif
-__device__ __forceinline__ int sgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ float sgpr(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 // number of set bits of `mask` below this lane
 __device__ __forceinline__ int rank_below(uint64_t mask) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0)); }
 
 template <bool MULTI>
-__device__ __forceinline__ void lidar_pool(const DeviceParams& P, const Lds& L, int ncars_here, int ci0, bool scan_lds)
+__device__ __forceinline__ void lidar_pool(const DeviceParams& P, const Lds& L, const LidarFrame* frames, float* scan_rows, int* pool,
+                                           int ncars_here, int ci0, bool scan_lds)
 {
     typedef const __attribute__((address_space(1))) unsigned char* global_u8;
     typedef const __attribute__((address_space(1))) uint16_t* global_u16;
@@ -143,14 +157,14 @@ __device__ __forceinline__ void lidar_pool(const DeviceParams& P, const Lds& L, 
                 // visible part of a car lies within `cull` of its origin, so a car whose origin is farther than that from the
                 // ray, behind its start, or beyond the wall hit cannot change the range.  Results are unaffected.
                 const FtgpVehicle& v = L.veh->v;
-                const LidarFrame* me = L.frame + c;
+                const LidarFrame* me = frames + c;
                 const float cull = L.veh->cull_radius;
                 const double lcx = me->lcx, lcy = me->lcy;
                 const float ox = (float)lcx - r0 * dxw, oy = (float)lcy - r0 * dyw;
                 const int slot0 = c - c % P.cars_per_env;
                 if (!me->finished)
                     for (int k = 0; k < P.cars_per_env; ++k) {
-                        const LidarFrame* b = L.frame + slot0 + k;
+                        const LidarFrame* b = frames + slot0 + k;
                         if (slot0 + k == c || b->finished) continue;          // shadowed cars are invisible (custom.py:1441-1466)
                         const float wx = (float)b->x - ox, wy = (float)b->y - oy;
                         const float along = wx * dxw + wy * dyw;
@@ -162,7 +176,7 @@ __device__ __forceinline__ void lidar_pool(const DeviceParams& P, const Lds& L, 
             }
             ranges[c * stride + j] = r;
             if (scan_lds) {          // the on-device driver only reads ranges[0] and ranges[eighth : n - eighth]
-                float* row = L.scan + c * win_floats;
+                float* row = scan_rows + c * win_floats;
                 const int jw = j - eighth;
                 if ((unsigned)jw < (unsigned)(R - 2 * eighth)) row[1 + jw] = r;
                 if (j == 0) row[0] = r;
@@ -174,13 +188,13 @@ __device__ __forceinline__ void lidar_pool(const DeviceParams& P, const Lds& L, 
             const uint64_t free_mask = __ballot(done);
             const int nfree = __popcll(free_mask);
             int base = 0;
-            if (lane == 0) base = atomicAdd(L.pool, nfree);
+            if (lane == 0) base = atomicAdd(pool, nfree);
             base = __builtin_amdgcn_readfirstlane(base);
             const int mine = base + rank_below(free_mask);
             if (done && mine < total) {
                 g = mine;
                 const int c = (int)__umulhi((uint32_t)mine, magic), j = mine - c * R;
-                const LidarFrame* fr = L.frame + c;
+                const LidarFrame* fr = frames + c;
                 const float4 f4 = *reinterpret_cast<const float4*>(fr);      // u0, v0, chf, shf
                 const float2 bd = L.ray[j];
                 dxw = fmaf(f4.z, bd.x, -(f4.w * bd.y));
@@ -366,12 +380,27 @@ __device__ __forceinline__ void car_contact(const DeviceParams& P, const FtgpVeh
     }
 }
 
+// LiDAR frame of a car at its current pose (lidar_car() of the oracle: centre, heading, binary32 pixel coordinates)
+__device__ __forceinline__ void frame_write(const DeviceParams& P, const FtgpVehicle& v, const CarCore* st, LidarFrame* fr)
+{
+    const double qw = st->qw, qz = st->qz;
+    const double ch = 1.0 - 2.0 * (qz * qz), sh = 2.0 * (qw * qz);
+    const double lcx = st->x + (ch * v.lidar_x - sh * v.lidar_y);
+    const double lcy = st->y + (sh * v.lidar_x + ch * v.lidar_y);
+    fr->u0 = (float)((lcx - P.origin_x) * P.inv_px_x);
+    fr->v0 = (float)((P.origin_y - lcy) * P.inv_px_y);
+    fr->chf = (float)ch; fr->shf = (float)sh;
+    fr->lcx = lcx; fr->lcy = lcy;
+    fr->x = st->x; fr->y = st->y; fr->qw = qw; fr->qz = qz;
+    fr->finished = st->finished;
+}
+
 // K1 + K3 for every car of the workgroup by ONE wave: K1 with one car per lane (all lanes read the pre-step states before
 // any lane commits, so multi-car envs need no staging buffer), then K3 with four lanes per car (25 centre-line points
 // each, first minimum wins).  steps += 1 happens between the two, as in custom.py:1425-1426 followed by the head of the
 // next loop iteration.
 template <bool MULTI>
-__device__ __forceinline__ void dynamics_lanes(const DeviceParams& P, const Lds& L, int ncars_here, int ci0)
+__device__ __forceinline__ void dynamics_lanes(const DeviceParams& P, const Lds& L, LidarFrame* next_frames, int ncars_here, int ci0)
 {
     const int lane = lane_id();
     const bool on = lane < ncars_here;
@@ -486,6 +515,9 @@ __device__ __forceinline__ void dynamics_lanes(const DeviceParams& P, const Lds&
         progress_update(P, r, L.steps[c], idx, best, P.cars[ci0 + c].times);
         race_store(r, sc);
     }
+    wave_lds_sync();
+    // the LiDAR frames of the next step (its sweep starts after the workgroup barrier that ends this step)
+    if (on) frame_write(P, L.veh->v, st, next_frames + lane);
 }
 
 // =============================================================================================
@@ -629,6 +661,16 @@ __device__ __forceinline__ void stage16(void* dst, const void* src, int bytes)
     for (int i = threadIdx.x; i < n; i += blockDim.x) d4[i] = s4[i];
 }
 
+// diagnostic build only (tools/stamps.sh): per-phase shader-clock totals over all workgroups and steps; never in the product
+#ifdef FTGP_STAMPS
+__device__ unsigned long long ftgp_stamps[16];
+#define STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define STAMP_ADD(slot, dt) stamp_acc[slot] += (unsigned long long)(dt)
+#else
+#define STAMP(var) do {} while (0)
+#define STAMP_ADD(slot, dt) do {} while (0)
+#endif
+
 #ifndef FTGP_WAVES_PER_EU
 #define FTGP_WAVES_PER_EU 8       // two 16-wave workgroups per CU: at most 64 VGPRs per lane
 #endif
@@ -636,7 +678,7 @@ template <bool MULTI>
 __global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(const DeviceParams* __restrict__ Pg, int policy, int n_steps)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    const DeviceParams& P = *reinterpret_cast<const DeviceParams*>(lds + Pg->off_params);   // valid after staging + barrier
+    const DeviceParams& P0 = *reinterpret_cast<const DeviceParams*>(lds + Pg->off_params);   // valid after staging + barrier
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = __builtin_amdgcn_readfirstlane(blockDim.x >> 6);
@@ -646,62 +688,84 @@ __global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(cons
     stage16(lds + Pg->off_path, Pg->path, Pg->off_ray - Pg->off_path);
     stage16(lds + Pg->off_ray, Pg->ray_dir, Pg->off_cars - Pg->off_ray);
     __syncthreads();
-    const Lds L = lds_view(P, lds);
-    const int cpb = P.cars_per_block;
+    const LdsOffsets off = lds_offsets(P0);
+    const int cpb = sgpr(P0.cars_per_block);
     const int ci0 = (int)blockIdx.x * cpb;
-    const int ncars_here = min(cpb, P.n_cars - ci0);
+    const int ncars_here = min(cpb, sgpr(P0.n_cars) - ci0);
     const bool need_scan = (policy == FTGP_POLICY_NIDC || policy == FTGP_POLICY_FAST);
+    {
+    const DeviceParams& P = P0;
+    const Lds L = lds_view(off, lds);
     const int R = P.n_rays, eighth = P.eighth, win_floats = P.win_floats;
-
     for (int c = wave; c < ncars_here; c += nwaves) {
         const int ci = ci0 + c;
         if (lane < (int)(sizeof(CarCore) / 4))
             reinterpret_cast<uint32_t*>(L.cars + c)[lane] = reinterpret_cast<const uint32_t*>(static_cast<const CarCore*>(&P.cars[ci]))[lane];
         if (lane == 0) L.steps[c] = P.steps[ci / P.cars_per_env];
-        if (need_scan) {
+        if (need_scan) {     // the scan of the previous launch is what the first driver call sees: buffer 1 = parity of step -1
             const float* my_ranges = P.ranges + (size_t)ci * P.ranges_stride;
-            float* row = L.scan + c * win_floats;
+            float* row = L.scan + (cpb + c) * win_floats;
             if (lane == 0) row[0] = my_ranges[0];
             for (int j = eighth + lane; j < R - eighth; j += FTGP_WAVE) row[1 + j - eighth] = my_ranges[j];
         }
+        wave_lds_sync();
+        if (lane == 0) frame_write(P, L.veh->v, L.cars + c, L.frame + c);
+    }
+    if (threadIdx.x < 4) L.pool[threadIdx.x] = 0;
     }
     __syncthreads();
 
+    // One workgroup barrier per step.  Inside a step, concurrently:
+    //   waves 0 .. cars-1  K5: driver of one car each on the scan of the PREVIOUS step (the other scan buffer) -> controls;
+    //                      the wave whose driver finishes last runs K1 + K3 for all cars (one car per lane) and writes the
+    //                      LiDAR frames of the NEXT step into the other frame buffer
+    //   every wave         K2: the sweep of THIS step from the current frame buffer (as soon as its driver work is done)
+    // The scan a driver sees lags the pose by one step (custom.py:1395-1425), which is what makes this legal: the sweep of
+    // step t needs only the pose of step t, and that depends on the controls of step t-1.
+#ifdef FTGP_STAMPS
+    unsigned long long stamp_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+#endif
     for (int it = 0; it < n_steps; ++it) {
-        // ---- phase A: driver and LiDAR frame, one wave per car
+        STAMP(t0);
+        // every step sees the parameter block and the LDS arrays through fresh, opaque offsets (see opaque())
+        const DeviceParams& P = *reinterpret_cast<const DeviceParams*>(lds + opaque(off.params));
+        const Lds L = lds_view(off, lds);
+        const int par = it & 1;
+        const int win_floats = sgpr(P.win_floats);
+        LidarFrame* frames = L.frame + par * cpb;
+        LidarFrame* next_frames = L.frame + (par ^ 1) * cpb;
+        float* scan_now = L.scan + par * cpb * win_floats;
+        float* scan_prev = L.scan + (par ^ 1) * cpb * win_floats;
         for (int c = wave; c < ncars_here; c += nwaves) {
-            CarCore* st = L.cars + c;
-            if (policy != FTGP_POLICY_HOST) {
-                policy_apply(P, policy, L.scan + c * win_floats, st, ci0 + c, L.steps[c], L.list + wave * FTGP_WAVE);
-                wave_lds_sync();
-            }
-            if (lane == 0) {
-                const FtgpVehicle& v = L.veh->v;
-                const double qw = st->qw, qz = st->qz;
-                const double ch = 1.0 - 2.0 * (qz * qz), sh = 2.0 * (qw * qz);
-                const double lcx = st->x + (ch * v.lidar_x - sh * v.lidar_y);
-                const double lcy = st->y + (sh * v.lidar_x + ch * v.lidar_y);
-                LidarFrame* fr = L.frame + c;
-                fr->u0 = (float)((lcx - P.origin_x) * P.inv_px_x);
-                fr->v0 = (float)((P.origin_y - lcy) * P.inv_px_y);
-                fr->chf = (float)ch; fr->shf = (float)sh;
-                fr->lcx = lcx; fr->lcy = lcy;
-                fr->x = st->x; fr->y = st->y; fr->qw = qw; fr->qz = qz;
-                fr->finished = st->finished;
+            if (policy != FTGP_POLICY_HOST) policy_apply(P, policy, scan_prev + c * win_floats, L.cars + c, ci0 + c, L.steps[c], L.list + wave * FTGP_WAVE);
+            wave_lds_sync();
+            int n = 0;
+            if (lane == 0) n = atomicAdd(L.pool + 2 + par, 1);
+            n = __builtin_amdgcn_readfirstlane(n);
+            STAMP(t1); STAMP_ADD(0, t1 - t0);
+            if (n == ncars_here - 1) {            // every driver of the workgroup has delivered its controls
+                if (lane == 0) { L.pool[par ^ 1] = 0; L.pool[2 + (par ^ 1)] = 0; }     // the next step's counters (idle during this step)
+#ifndef FTGP_ABLATE_K1
+                dynamics_lanes<MULTI>(P, L, next_frames, ncars_here, ci0);
+#endif
+                STAMP(t2); STAMP_ADD(2, t2 - t1); STAMP_ADD(7, 1);
             }
         }
-        if (threadIdx.x == 0) *L.pool = 0;
-        __syncthreads();
-        // ---- phase B: dynamics of all cars on one wave, the sweep on every wave
-#ifndef FTGP_ABLATE_K1
-        if (wave == 0) dynamics_lanes<MULTI>(P, L, ncars_here, ci0);
-#endif
+        STAMP(t3);
 #ifndef FTGP_ABLATE_K2
-        lidar_pool<MULTI>(P, L, ncars_here, ci0, need_scan);
+        lidar_pool<MULTI>(P, L, frames, scan_now, L.pool + par, ncars_here, ci0, need_scan);
 #endif
+        STAMP(t4);
         __syncthreads();
+        STAMP(t5);
+        STAMP_ADD(3, t4 - t3); STAMP_ADD(4, t5 - t4); STAMP_ADD(5, 1); STAMP_ADD(6, t5 - t0);
     }
 
+#ifdef FTGP_STAMPS
+    if (lane == 0) for (int q = 0; q < 8; ++q) atomicAdd(&ftgp_stamps[q], stamp_acc[q]);
+#endif
+    const DeviceParams& P = P0;
+    const Lds L = lds_view(off, lds);
     for (int c = wave; c < ncars_here; c += nwaves) {
         const int ci = ci0 + c;
         if (lane < (int)(sizeof(CarCore) / 4))
@@ -868,18 +932,17 @@ __global__ void ftgp_fakelidar_kernel(const double* __restrict__ dt, int H, int 
     scan[i] = distance; points[2 * i] = x; points[2 * i + 1] = y;
 }
 
-// Octant box field build (ftgp_create): one cell of one plane per lane, ring included.
-__global__ void ftgp_box_field_kernel(const uint8_t* __restrict__ ksq, const uint16_t* __restrict__ runx, const uint16_t* __restrict__ runy,
-                                      int W, int H, uint16_t* __restrict__ out)
+// Sector box field build (ftgp_create): one cell of one plane per lane, ring included.
+__global__ void ftgp_box_field_kernel(const uint16_t* __restrict__ runx, const uint16_t* __restrict__ runy, int W, int H, uint16_t* __restrict__ out)
 {
     const size_t cells = (size_t)(W + 2) * (H + 2);
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= cells * FTGP_OCTANTS) return;
-    const int oct = (int)(i / cells);
-    const size_t c = i - (size_t)oct * cells;
+    if (i >= cells * FTGP_SECTORS) return;
+    const int sector = (int)(i / cells);
+    const size_t c = i - (size_t)sector * cells;
     const int X = (int)(c % (size_t)(W + 2)), Y = (int)(c / (size_t)(W + 2));
     uint32_t e = FTGP_FIELD_OUT;
-    if (X >= 1 && X <= W && Y >= 1 && Y <= H) e = ftgp_box_entry(ksq, runx, runy, W, H, X - 1, Y - 1, oct);
+    if (X >= 1 && X <= W && Y >= 1 && Y <= H) e = ftgp_box_entry(runx, runy, W, H, X - 1, Y - 1, sector);
     out[i] = (uint16_t)e;
 }
 

@@ -7,13 +7,16 @@
 // Nothing accumulates, so any march that skips wall-free cells and re-synchronises with these comparisons returns the
 // same bits.
 //
-// Octant box field.  Both axes are mirrored so that every ray travels towards +x', +y' (x' = -x is exact in IEEE
-// arithmetic and maps cell i to ~i).  For each pixel and each of the 8 direction octants (mirror x, mirror y, dominant
-// axis) one 16-bit entry holds a wall-free box of pixels with its corner at the pixel, extending AHEAD of the ray:
-// low byte kx, high byte ky (cells along x' / y').  0 = the pixel is a wall.  The planes carry a one-pixel ring around
-// the image whose entries are FTGP_FIELD_OUT (kx = 0 terminates the march, ky = 1 tells it from a wall), and every box
-// is clipped at the image edge, so a ray that leaves the image lands exactly on a ring cell: the march needs no
-// bounds test and no direction-dependent select.
+// Sector box field.  Both axes are mirrored so that every ray travels towards +x', +y' (x' = -x is exact in IEEE
+// arithmetic and maps cell i to ~i).  Directions are binned into FTGP_SECTORS sectors: the octant (mirror x, mirror y,
+// dominant axis) and, with 16 sectors, whether the slope minor/major is above 1/2.  For each pixel and sector one 16-bit
+// entry holds a box of pixels with its corner at the pixel, extending AHEAD of the ray: low byte kx, high byte ky (cells
+// along x' / y'); 0 = the pixel is a wall.  Only the part of the box that a ray of the sector can reach from anywhere
+// inside the pixel has to be wall-free (the cone of the sector, widened by one cell so that rays through pixel corners --
+// ties of the DDA -- and binary32 rounding stay inside it); walls beside or behind the cone never shorten a jump.
+// The planes carry a one-pixel ring around the image whose entries are FTGP_FIELD_OUT (kx = 0 terminates the march,
+// ky = 1 tells it from a wall), and every box is clipped at the image edge, so a ray that leaves the image lands exactly
+// on a ring cell: the march needs no bounds test and no direction-dependent select.
 #pragma once
 #include <math.h>
 #include <stdint.h>
@@ -25,44 +28,58 @@
 #endif
 
 #define FTGP_FIELD_OUT 0x0100u
-#define FTGP_OCTANTS 8
+#ifndef FTGP_SECTORS
+#define FTGP_SECTORS 16
+#endif
 
-// Entry of pixel (x, y) for octant oct = (mirror x) | (mirror y) << 1 | (y-dominant) << 2.
-//   ksq[q][y][x]  side of the largest wall-free square with its corner at the pixel, extending towards quadrant q
-//                 (pixels beyond the image count as free; 0 on walls; clamped to 255)
-//   runx[d][y][x] wall-free run length starting at the pixel along +x (d = 0) / -x (d = 1); runy likewise (65535 = to the edge and beyond)
-// Per octant the box is the square or, when it reaches farther along the dominant axis, the largest 2h x h rectangle
-// (2h along the dominant axis), found by walking h rows (columns) with a running minimum of the run lengths.
-FTGP_HD uint32_t ftgp_box_entry(const uint8_t* ksq, const uint16_t* runx, const uint16_t* runy, int W, int H, int x, int y, int oct)
+// Entry of pixel (x, y) for sector = (mirror x) | (mirror y) << 1 | (y-dominant) << 2 | (slope > 1/2) << 3.
+//   runx[d][y][x] wall-free run length starting at the pixel along +x (d = 0) / -x (d = 1); runy likewise
+//                 (0 on walls; 65535 = to the image edge and beyond)
+// In (major A, minor B) coordinates of the sector a ray that starts anywhere in cell (0, 0) with slope in [lo, hi] can
+// only be in row j of column i if  lo * (i - 1) - 1 <= j <= hi * (i + 1) + 1  (closed: corner touches count).  For every
+// box height kB the widest admissible kA is the first wall met by the reachable part of rows 0 .. kB - 1; the pair that
+// maximises the travel min(kA, kB / slope) summed over four slopes of the sector is stored.
+FTGP_HD uint32_t ftgp_box_entry(const uint16_t* runx, const uint16_t* runy, int W, int H, int x, int y, int sector)
 {
-    const size_t plane = (size_t)W * H, i = (size_t)y * W + x;
-    const int q = oct & 3, dom = oct >> 2;
-    const int k = ksq[(size_t)q * plane + i];
-    if (k == 0) return 0u;
+    const size_t plane = (size_t)W * H;
+    if (runx[(size_t)y * W + x] == 0) return 0u;                 // wall
+    const int q = sector & 3, dom = (sector >> 2) & 1, steep = (sector >> 3) & 1;
     const int sx = (q & 1) ? -1 : 1, sy = (q & 2) ? -1 : 1;
-    const uint16_t* rx = runx + ((q & 1) ? plane : 0);
-    const uint16_t* ry = runy + ((q & 2) ? plane : 0);
-    int h = 0, m = 65535;
-    for (; h < 127; ++h) {
-        int r;
-        if (dom == 0) { const int yy = y + sy * h; r = (yy >= 0 && yy < H) ? (int)rx[(size_t)yy * W + x] : 65535; }
-        else          { const int xx = x + sx * h; r = (xx >= 0 && xx < W) ? (int)ry[(size_t)y * W + xx] : 65535; }
-        m = r < m ? r : m;
-        if (m < 2 * (h + 1)) break;
+    const int ax = dom == 0 ? sx : 0, ay = dom == 0 ? 0 : sy;    // unit step along the major / minor axis
+    const int bx = dom == 0 ? 0 : sx, by = dom == 0 ? sy : 0;
+    const uint16_t* run = dom == 0 ? runx + ((q & 1) ? plane : 0) : runy + ((q & 2) ? plane : 0);
+    // distance to the image edge: boxes stop there, so that the cell after the box is a ring cell
+    const int eX = sx > 0 ? W - x : x + 1, eY = sy > 0 ? H - y : y + 1;
+    const int eA = dom == 0 ? eX : eY, eB = dom == 0 ? eY : eX;
+    // sample slopes of the sector, as travel = min(cA * kA, cB[k] * kB) with integer coefficients
+    long cA, cB0, cB1, cB2, cB3;
+    if (FTGP_SECTORS == 8) { cA = 105; cB0 = 840; cB1 = 280; cB2 = 168; cB3 = 120; }                 // 1/8, 3/8, 5/8, 7/8
+    else if (!steep)       { cA = 105; cB0 = 1680; cB1 = 560; cB2 = 336; cB3 = 240; }                // 1/16, 3/16, 5/16, 7/16
+    else                   { cA = 45045; cB0 = 80080; cB1 = 65520; cB2 = 55440; cB3 = 48048; }       // 9/16, 11/16, 13/16, 15/16
+    long best = -1; int bA = 1, bB = 1, m = 65535;
+    for (int j = 0; j < 255 && j < eB; ++j) {
+        // first column of row j that a ray of the sector can reach:  j <= hi * (i + 1) + 1
+        int cj = (FTGP_SECTORS == 16 && !steep) ? 2 * j - 3 : j - 2;
+        cj = cj < 0 ? 0 : cj;
+        const int px = x + ax * cj + bx * j, py = y + ay * cj + by * j;
+        int lim = 65535;                                          // column of the first wall of the reachable part of row j
+        if (px >= 0 && px < W && py >= 0 && py < H) { const int r = run[(size_t)py * W + px]; if (r < 65535) lim = cj + r; }
+        if (FTGP_SECTORS == 16 && steep && lim > 2 * j + 3) lim = 65535;      // ... and the last one: j >= lo * (i - 1) - 1
+        m = lim < m ? lim : m;
+        if (4 * cA * (long)m <= best) break;                      // no taller box can do better
+        int kA = m < 255 ? m : 255; kA = kA < eA ? kA : eA;
+        const int kB = j + 1;
+        const long a = cA * kA;
+        const long b0 = cB0 * kB, b1 = cB1 * kB, b2 = cB2 * kB, b3 = cB3 * kB;
+        const long score = (a < b0 ? a : b0) + (a < b1 ? a : b1) + (a < b2 ? a : b2) + (a < b3 ? a : b3);
+        if (score > best) { best = score; bA = kA; bB = kB; }
     }
-    const int ks = k < 127 ? k : 127;
-    int kmaj = ks, kmin = ks;
-    if (2 * h > ks) { kmaj = 2 * h; kmin = h; }
-    int kx = dom == 0 ? kmaj : kmin, ky = dom == 0 ? kmin : kmaj;
-    // clip at the image edge: the cell after the box is then a ring cell
-    const int ex = sx > 0 ? W - x : x + 1, ey = sy > 0 ? H - y : y + 1;
-    kx = kx < ex ? kx : ex; ky = ky < ey ? ky : ey;
-    kx = kx < 255 ? kx : 255; ky = ky < 255 ? ky : 255;
+    const int kx = dom == 0 ? bA : bB, ky = dom == 0 ? bB : bA;
     return (uint32_t)kx | ((uint32_t)ky << 8);
 }
 
 // One ray in the mirrored frame.  mx / my (0 or -1) turn the mirrored cell back into the true pixel (ix ^ mx, iy ^ my);
-// byte offset of its entry = offC + 2 * ((iy ^ my) * fstride + (ix ^ mx)), offC = start of the octant's plane + the ring.
+// byte offset of its entry = offC + 2 * ((iy ^ my) * fstride + (ix ^ mx)), offC = start of the sector's plane + the ring.
 struct FtgpRay {
     float pum, pvm, dum, dvm, ivx, ivy;   // mirrored origin, |direction|, |1 / direction| (+inf where the direction is 0)
     float s, result;                      // crossing time of the last step; range (-1: none yet / off the image)
@@ -92,10 +109,11 @@ FTGP_HD void ftgp_ray_init(FtgpRay& r, float pu, float pv, float du, float dv, i
     r.ivx = fabsf(1.0f / du);          // IEEE division: +inf where the direction is 0 (that axis is never stepped)
     r.ivy = fabsf(1.0f / dv);
     r.s = 0.0f; r.result = -1.0f;
-    const int oct = (mx ? 1 : 0) | (my ? 2 : 0) | (dom << 2);
+    int sector = (mx ? 1 : 0) | (my ? 2 : 0) | (dom << 2);
+    if (FTGP_SECTORS == 16) sector |= (2.0f * (dom ? adu : adv) > (dom ? adv : adu)) ? 8 : 0;      // slope minor / major above 1/2
     r.mx = mx ? -1 : 0; r.my = my ? -1 : 0;
     r.ix = ix0 ^ r.mx; r.iy = iy0 ^ r.my;
-    r.offC = (int)((uint32_t)oct * plane_bytes) + 2 * (fstride + 1);
+    r.offC = (int)((uint32_t)sector * plane_bytes) + 2 * (fstride + 1);
     if (!inside) { r.ix = r.iy = 0; r.offC = 0; r.mx = r.my = 0; }       // starts off the image: ring cell (0, 0), result stays -1
 }
 

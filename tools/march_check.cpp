@@ -38,12 +38,12 @@ int main(int argc, char** argv)
     HostTables g; build_tables(t, 3, g);
     const int W = t.width, H = t.height;
     const size_t cells = (size_t)(W + 2) * (H + 2);
-    std::vector<uint16_t> field(cells * FTGP_OCTANTS, (uint16_t)FTGP_FIELD_OUT);
+    std::vector<uint16_t> field(cells * FTGP_SECTORS, (uint16_t)FTGP_FIELD_OUT);
     long gw_bad = 0;
-    for (int oct = 0; oct < FTGP_OCTANTS; ++oct)
+    for (int oct = 0; oct < FTGP_SECTORS; ++oct)
         for (int y = 0; y < H; ++y)
             for (int x = 0; x < W; ++x) {
-                const uint32_t e = ftgp_box_entry(g.ksq.data(), g.runx.data(), g.runy.data(), W, H, x, y, oct);
+                const uint32_t e = ftgp_box_entry(g.runx.data(), g.runy.data(), W, H, x, y, oct);
                 field[(size_t)oct * cells + (size_t)(y + 1) * (W + 2) + (x + 1)] = (uint16_t)e;
                 if ((e == 0) != wall_at(t, x, y) || (e != 0 && (e & 255u) == 0)) ++gw_bad;      // 0 <=> wall; a free cell never carries kx = 0
             }

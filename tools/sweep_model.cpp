@@ -14,30 +14,12 @@
 #include "../include/ftgp.h"
 #include "../ft_grandprix_amd/csrc/ftgp_march.h"
 
-struct Tables { std::vector<uint8_t> wall, ksq; std::vector<uint16_t> runx, runy; };
+struct Tables { std::vector<uint8_t> wall; std::vector<uint16_t> runx, runy; };
 static void build(const std::vector<uint32_t>& bits, int W, int H, int wpr, Tables& g)
 {
     g.wall.assign((size_t)W * H, 0);
     for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) if ((bits[(size_t)y * wpr + (x >> 5)] >> (x & 31)) & 1u) g.wall[(size_t)y * W + x] = 1;
     const size_t plane = (size_t)W * H;
-    g.ksq.assign(4 * plane, 0);
-    std::vector<int> prev((size_t)W + 2), cur((size_t)W + 2);
-    for (int q = 0; q < 4; ++q) {
-        const int sx = (q & 1) ? -1 : 1, sy = (q & 2) ? -1 : 1;
-        std::fill(prev.begin(), prev.end(), 1 << 20);
-        for (int yy = 0; yy < H; ++yy) {
-            const int y = sy > 0 ? H - 1 - yy : yy;
-            std::fill(cur.begin(), cur.end(), 1 << 20);
-            for (int xx = 0; xx < W; ++xx) {
-                const int x = sx > 0 ? W - 1 - xx : xx;
-                int v = 0;
-                if (!g.wall[(size_t)y * W + x]) v = 1 + std::min(std::min(cur[(size_t)(x + sx + 1)], prev[(size_t)(x + 1)]), prev[(size_t)(x + sx + 1)]);
-                cur[(size_t)(x + 1)] = v;
-                g.ksq[(size_t)q * plane + (size_t)y * W + x] = (uint8_t)std::min(255, v);
-            }
-            std::swap(prev, cur);
-        }
-    }
     g.runx.assign(2 * plane, 0); g.runy.assign(2 * plane, 0);
     for (int y = 0; y < H; ++y) {
         int r = 65535;
@@ -71,9 +53,9 @@ int main(int argc, char** argv)
     const float eps = ldexpf(1.0f, -(argc > 7 ? atoi(argv[7]) : 9));
     Tables g; build(bits, W, H, wpr, g);
     const size_t cells = (size_t)(W + 2) * (H + 2);
-    std::vector<uint16_t> field(cells * FTGP_OCTANTS, (uint16_t)FTGP_FIELD_OUT);
-    for (int oct = 0; oct < FTGP_OCTANTS; ++oct) for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x)
-        field[(size_t)oct * cells + (size_t)(y + 1) * (W + 2) + (x + 1)] = (uint16_t)BOX_ENTRY(g.ksq.data(), g.runx.data(), g.runy.data(), W, H, x, y, oct);
+    std::vector<uint16_t> field(cells * FTGP_SECTORS, (uint16_t)FTGP_FIELD_OUT);
+    for (int oct = 0; oct < FTGP_SECTORS; ++oct) for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x)
+        field[(size_t)oct * cells + (size_t)(y + 1) * (W + 2) + (x + 1)] = (uint16_t)BOX_ENTRY(g.runx.data(), g.runy.data(), W, H, x, y, oct);
     const int fstride = W + 2; const uint32_t plane_bytes = 2u * (uint32_t)fstride * (uint32_t)(H + 2);
     std::vector<float> bx(R), by(R);
     for (int j = 0; j < R; ++j) { const double phi = ((360.0 / R) * j - 90.0) * (M_PI / 180.0); bx[j] = (float)sin(phi); by[j] = (float)(-cos(phi)); }
