@@ -69,7 +69,7 @@ API_SYMBOLS = (
     "default_vehicle", "last_error", "device_count", "create", "destroy", "reset", "set_ctrl", "step",
     "rollout", "get_lidar", "get_snapshot", "get_pose", "get_progress", "get_lap_times", "get_ctrl",
     "get_steps", "set_pose", "policy_eval", "eval_progress", "metrics_local", "comm_unique_id", "comm_init", "metrics_allgather",
-    "last_kernel_ms", "kernel_name", "fakelidar",
+    "last_kernel_ms", "kernel_name", "fakelidar", "selftest",
 )
 
 
@@ -130,6 +130,7 @@ class CLib:
             "fakelidar": (i32, [i32, dp, i32, i32, i32, dp, i32, dp, dp, C.c_double, dp, dp]),
             "last_kernel_ms": (i32, [vp, C.POINTER(C.c_float)]),
             "kernel_name": (C.c_char_p, [vp]),
+            "selftest": (i32, [i32, C.POINTER(C.c_int64)]),
         }
         for name, (res, args) in sigs.items():
             if name == "fakelidar" and self.prefix != "ftgp_":
@@ -333,6 +334,13 @@ def fakelidar(lib: CLib, dt: np.ndarray, origins: np.ndarray, cosines: np.ndarra
                                           c[k].ctypes.data_as(C.c_void_p), s[k].ctypes.data_as(C.c_void_p), float(eps),
                                           scan[k].ctypes.data_as(C.c_void_p), pts[k].ctypes.data_as(C.c_void_p)))
     return scan, pts
+
+
+def selftest(lib: CLib, device_id: int = 0) -> int:
+    """Mismatches of the device self-test (``ftgp_selftest``); 0 is the only acceptable answer."""
+    n = C.c_int64(-1)
+    lib.check(lib.fn("selftest")(device_id, C.byref(n)))
+    return int(n.value)
 
 
 def comm_unique_id(lib: CLib) -> bytes:

@@ -319,7 +319,7 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
     P.seed = cfg->seed; P.dt = cfg->dt;
     P.bubble_wrap = cfg->bubble_wrap ? 1 : 0;        // cfg->naive_flatten: accepted, no effect on a planar model (custom.py:1338-1339)
     P.width = t.width; P.height = t.height; P.words_per_row = t.words_per_row; P.fstride = t.width + 2;
-    P.plane_bytes = 2u * (uint32_t)(t.width + 2) * (uint32_t)(t.height + 2);
+    P.plane256 = ftgp_plane256(t.width, t.height);
     P.px_size_x = t.px_size_x; P.px_size_y = t.px_size_y; P.origin_x = t.origin_x; P.origin_y = t.origin_y;
     P.inv_px_x = 1.0 / t.px_size_x; P.inv_px_y = 1.0 / t.px_size_y;
     P.inv_px_x_f = (float)P.inv_px_x; P.inv_px_y_f = (float)P.inv_px_y;
@@ -337,7 +337,7 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
     }
     P.eighth = (int)((double)cfg->n_rays / 8.0);                    // nidc.py:18
     P.win_floats = (1 + (cfg->n_rays - 2 * P.eighth) + 3) & ~3;
-    P.snap_eps = 1.0f / 512.0f;
+    P.snap_eps = ftgp_snap_eps(t.width, t.height);
     P.ray_magic = (uint32_t)((0x100000000ull + (uint64_t)cfg->n_rays - 1) / (uint64_t)cfg->n_rays);
 
     // workgroup shape: whole envs, at most 16 cars (K1 / K3 run on the lanes of one wave), two workgroups per CU
@@ -391,7 +391,7 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
 
     {   // sector box field: upload the run lengths, search the boxes on the device
         const size_t plane = (size_t)t.width * t.height;
-        const size_t cells = (size_t)(t.width + 2) * (t.height + 2) * FTGP_SECTORS;
+        const size_t cells = (size_t)P.plane256 * 128 * FTGP_SECTORS;
         uint16_t* d_runx = nullptr; uint16_t* d_runy = nullptr;
         CREATE_TRY(hipMalloc(&e->d_field, cells * sizeof(uint16_t)));
         CREATE_TRY(hipMalloc(&d_runx, 2 * plane * sizeof(uint16_t)));
@@ -734,6 +734,25 @@ int ftgp_debug_stamps(unsigned long long* out)
     return hipMemcpyToSymbol(HIP_SYMBOL(ftgp_stamps), z, sizeof z) == hipSuccess ? 0 : -1;
 }
 #endif
+
+int ftgp_selftest(int device_id, int64_t* mismatches)
+{
+    if (!mismatches) return fail(FTGP_ERR_ARG, "null argument%s");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(FTGP_ERR_NO_DEVICE, "no HIP device: this library has no CPU fallback%s");
+    if (device_id < 0 || device_id >= ndev) return fail(FTGP_ERR_ARG, "device_id out of range%s");
+    HIP_TRY(hipSetDevice(device_id));
+    unsigned long long* d = nullptr; unsigned long long h = 0;
+    HIP_TRY(hipMalloc(&d, sizeof h));
+    hipError_t e1 = hipMemset(d, 0, sizeof h);
+    hipLaunchKernelGGL(ftgp_selftest_rcp_kernel, dim3(1u << 12), dim3(256), 0, 0, d);
+    hipError_t e2 = hipGetLastError();
+    hipError_t e3 = hipMemcpy(&h, d, sizeof h, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return fail(FTGP_ERR_HIP, "selftest: HIP error%s");
+    *mismatches = (int64_t)h;
+    return 0;
+}
 
 const char* ftgp_kernel_name(FtgpEnv* e)
 {

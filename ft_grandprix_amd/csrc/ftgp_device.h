@@ -50,7 +50,7 @@ struct DeviceParams {
     float inv_px_x_f, inv_px_y_f;
     float snap_eps;               // the march re-checks a landing point with the exact comparisons within this distance of a pixel boundary
     uint32_t ray_magic;           // ceil(2^32 / n_rays): pool index -> (car slot, ray) without a division
-    uint32_t plane_bytes;         // bytes per sector plane of the box field
+    uint32_t plane256;            // bytes per (padded) sector plane of the box field / 256
     int32_t contact_reach;        // chessboard reach (pixels) of the wall-contact window; `nearbits` is the wall set dilated by it
     // step-kernel launch shape and LDS layout (byte offsets, all 16-B aligned)
     int32_t cars_per_block, waves_per_block, eighth, win_floats;   // win_floats: floats per LDS scan row = 1 + (n_rays - 2*eighth), padded to 4

@@ -124,6 +124,20 @@ __device__ __forceinline__ float ray_vs_car(const FtgpVehicle& v, const LidarFra
 // number of set bits of `mask` below this lane
 __device__ __forceinline__ int rank_below(uint64_t mask) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0)); }
 
+// |1 / x| correctly rounded, as the specification's IEEE division gives it.  One Newton step on v_rcp_f32 (1 ulp) with
+// fused residuals is correctly rounded for every binary32 input of normal magnitude (checked exhaustively over all 2^32
+// bit patterns by ftgp_selftest / tests/test_gpu_parity.py); zeros, denormals and huge values take the division.
+__device__ __forceinline__ float rcp_abs(float x)
+{
+    const float ax = fabsf(x);
+    float y = __builtin_amdgcn_rcpf(ax);
+    const float e = fmaf(-ax, y, 1.0f);
+    y = fmaf(y, e, y);
+    const bool odd = !(ax > 0x1p-100f && ax < 0x1p100f);      // also true for a NaN
+    if (__any(odd)) { const float z = fabsf(1.0f / x); y = odd ? z : y; }
+    return y;
+}
+
 template <bool MULTI>
 __device__ __forceinline__ void lidar_pool(const DeviceParams& P, const Lds& L, const LidarFrame* frames, float* scan_rows, int* pool,
                                            int ncars_here, int ci0, bool scan_lds)
@@ -134,7 +148,7 @@ __device__ __forceinline__ void lidar_pool(const DeviceParams& P, const Lds& L, 
     // wave-uniform constants of the sweep, pinned in SGPRs (they come out of the LDS parameter block, i.e. out of VGPRs)
     const int R = sgpr(P.n_rays), total = ncars_here * R;
     const int W = sgpr(P.width), H = sgpr(P.height), fstride = sgpr(P.fstride), stride = sgpr(P.ranges_stride);
-    const uint32_t plane_bytes = (uint32_t)sgpr((int)P.plane_bytes), magic = (uint32_t)sgpr((int)P.ray_magic);
+    const uint32_t plane256 = (uint32_t)sgpr((int)P.plane256), magic = (uint32_t)sgpr((int)P.ray_magic);
     const int eighth = sgpr(P.eighth), win_floats = sgpr(P.win_floats);
     const float isx = sgpr(P.inv_px_x_f), isy = sgpr(P.inv_px_y_f), eps = sgpr(P.snap_eps);
     const float r0 = sgpr((float)L.veh->v.lidar_ring_radius);
@@ -144,13 +158,13 @@ __device__ __forceinline__ void lidar_pool(const DeviceParams& P, const Lds& L, 
 
     FtgpRay ray; ftgp_ray_park(ray, -1.0f);
     float dxw = 0.0f, dyw = 0.0f;
-    int g = -1;                      // pool index of the ray this lane is marching (or has just finished); -1: none
+    int cj = -1;                     // (car slot << 16 | ray) of the ray this lane is marching (or has just finished); -1: none
     bool done = true;                // the lane's ray sits on its terminal cell (or the lane has none)
     bool pool_empty = false;         // wave-uniform
     for (int round = 0; round < (1 << 20); ++round) {
         // ---- finished rays: store the range ...
-        if (done && g >= 0) {
-            const int c = (int)__umulhi((uint32_t)g, magic), j = g - c * R;
+        if (done && cj >= 0) {
+            const int c = cj >> 16, j = cj & 0xffff;
             float r = ray.result;
             if (MULTI) {
                 // Rays also see the other cars of the env (a9).  Conservative cull before the exact box / puck tests: every
@@ -174,28 +188,36 @@ __device__ __forceinline__ void lidar_pool(const DeviceParams& P, const Lds& L, 
                         if (rc < INFINITY && (r < 0.0f || rc < r)) r = rc;
                     }
             }
-            ranges[c * stride + j] = r;
+            ranges[__mul24(c, stride) + j] = r;
             if (scan_lds) {          // the on-device driver only reads ranges[0] and ranges[eighth : n - eighth]
-                float* row = scan_rows + c * win_floats;
+                float* row = scan_rows + __mul24(c, win_floats);
                 const int jw = j - eighth;
                 if ((unsigned)jw < (unsigned)(R - 2 * eighth)) row[1 + jw] = r;
                 if (j == 0) row[0] = r;
             }
-            g = -1;
+            cj = -1;
         }
-        // ---- ... and take the next rays of the pool
+        // ---- ... and take the next rays of the pool: the free lanes get consecutive pool indices base, base + 1, ...
         if (!pool_empty) {
             const uint64_t free_mask = __ballot(done);
             const int nfree = __popcll(free_mask);
             int base = 0;
             if (lane == 0) base = atomicAdd(pool, nfree);
             base = __builtin_amdgcn_readfirstlane(base);
-            const int mine = base + rank_below(free_mask);
-            if (done && mine < total) {
-                g = mine;
-                const int c = (int)__umulhi((uint32_t)mine, magic), j = mine - c * R;
-                const LidarFrame* fr = frames + c;
-                const float4 f4 = *reinterpret_cast<const float4*>(fr);      // u0, v0, chf, shf
+            const int rank = rank_below(free_mask);
+            // pool index -> (car slot, ray): one scalar division for the batch; a batch spans at most two cars when R >= 64
+            int c, j;
+            if (R >= FTGP_WAVE) {
+                const int c0 = (int)__umulhi((uint32_t)base, magic), j0 = base - c0 * R;
+                j = j0 + rank;
+                const bool wrap = j >= R;
+                c = wrap ? c0 + 1 : c0; j = wrap ? j - R : j;
+            } else {
+                c = (int)__umulhi((uint32_t)(base + rank), magic); j = base + rank - c * R;
+            }
+            if (done && base + rank < total) {
+                cj = (c << 16) | j;
+                const float4 f4 = *reinterpret_cast<const float4*>(frames + c);      // u0, v0, chf, shf
                 const float2 bd = L.ray[j];
                 dxw = fmaf(f4.z, bd.x, -(f4.w * bd.y));
                 dyw = fmaf(f4.w, bd.x, f4.z * bd.y);
@@ -203,12 +225,14 @@ __device__ __forceinline__ void lidar_pool(const DeviceParams& P, const Lds& L, 
                 const float dv = -(dyw * isy);
                 const float pu = fmaf(du, -r0, f4.x);
                 const float pv = fmaf(dv, -r0, f4.y);
-                ftgp_ray_init(ray, pu, pv, du, dv, W, H, fstride, plane_bytes);
-                if (fr->finished) ftgp_ray_park(ray, 0.0f);                   // a finished car's rangefinders are switched off (custom.py:1436-1439)
+                ftgp_ray_init(ray, pu, pv, du, dv, rcp_abs(du), rcp_abs(dv), W, H, fstride, plane256);
+                // a finished car's rangefinders are switched off (custom.py:1436-1439): its frame carries u0 = -inf, so the ray is
+                // parked like any ray that starts off the image, and reads 0 instead of -1
+                ray.result = (f4.x == -INFINITY) ? 0.0f : -1.0f;
             }
             pool_empty = base + nfree >= total;
         }
-        if (!__any(g >= 0)) break;       // nothing in flight and nothing left to hand out
+        if (!__any(cj >= 0)) break;      // nothing in flight and nothing left to hand out
         // ---- march until enough lanes are free to make a batched refill worthwhile (or, at the end, until all are done)
         const int want = pool_empty ? FTGP_WAVE : FTGP_REFILL;
         for (int guard = 0; guard < 4 * 8192; ++guard) {
@@ -222,6 +246,21 @@ __device__ __forceinline__ void lidar_pool(const DeviceParams& P, const Lds& L, 
             if (__popcll(done_mask) >= want) { done = (done_mask >> lane) & 1ull; break; }
         }
     }
+}
+
+// device arithmetic the kernels rely on, checked over every binary32 bit pattern: rcp_abs(x) == |1 / x| (IEEE division)
+__global__ void ftgp_selftest_rcp_kernel(unsigned long long* __restrict__ mismatches)
+{
+    unsigned long long bad = 0;
+    const uint32_t per = 1u << 12;                                     // 2^20 threads x 2^12 patterns
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    for (uint32_t k = 0; k < per; ++k) {
+        const float x = __uint_as_float(t * per + k);
+        const float a = rcp_abs(x), b = fabsf(1.0f / x);
+        const bool same = __float_as_uint(a) == __float_as_uint(b) || (a != a && b != b);
+        bad += same ? 0 : 1;
+    }
+    if (bad) atomicAdd(mismatches, bad);
 }
 
 // =============================================================================================
@@ -387,12 +426,13 @@ __device__ __forceinline__ void frame_write(const DeviceParams& P, const FtgpVeh
     const double ch = 1.0 - 2.0 * (qz * qz), sh = 2.0 * (qw * qz);
     const double lcx = st->x + (ch * v.lidar_x - sh * v.lidar_y);
     const double lcy = st->y + (sh * v.lidar_x + ch * v.lidar_y);
-    fr->u0 = (float)((lcx - P.origin_x) * P.inv_px_x);
+    const int finished = st->finished;
+    fr->u0 = finished ? -INFINITY : (float)((lcx - P.origin_x) * P.inv_px_x);     // -inf: rangefinders switched off (see lidar_pool)
     fr->v0 = (float)((P.origin_y - lcy) * P.inv_px_y);
     fr->chf = (float)ch; fr->shf = (float)sh;
     fr->lcx = lcx; fr->lcy = lcy;
     fr->x = st->x; fr->y = st->y; fr->qw = qw; fr->qz = qz;
-    fr->finished = st->finished;
+    fr->finished = finished;
 }
 
 // K1 + K3 for every car of the workgroup by ONE wave: K1 with one car per lane (all lanes read the pre-step states before
@@ -736,6 +776,10 @@ __global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(cons
         LidarFrame* next_frames = L.frame + (par ^ 1) * cpb;
         float* scan_now = L.scan + par * cpb * win_floats;
         float* scan_prev = L.scan + (par ^ 1) * cpb * win_floats;
+#ifndef FTGP_NO_PRIO
+        // the driver -> dynamics chain is the latency-critical path of a step and a small share of its instructions: let it issue first
+        if (wave < ncars_here) __builtin_amdgcn_s_setprio(3);
+#endif
         for (int c = wave; c < ncars_here; c += nwaves) {
             if (policy != FTGP_POLICY_HOST) policy_apply(P, policy, scan_prev + c * win_floats, L.cars + c, ci0 + c, L.steps[c], L.list + wave * FTGP_WAVE);
             wave_lds_sync();
@@ -751,6 +795,9 @@ __global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(cons
                 STAMP(t2); STAMP_ADD(2, t2 - t1); STAMP_ADD(7, 1);
             }
         }
+#ifndef FTGP_NO_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         STAMP(t3);
 #ifndef FTGP_ABLATE_K2
         lidar_pool<MULTI>(P, L, frames, scan_now, L.pool + par, ncars_here, ci0, need_scan);
@@ -935,7 +982,7 @@ __global__ void ftgp_fakelidar_kernel(const double* __restrict__ dt, int H, int 
 // Sector box field build (ftgp_create): one cell of one plane per lane, ring included.
 __global__ void ftgp_box_field_kernel(const uint16_t* __restrict__ runx, const uint16_t* __restrict__ runy, int W, int H, uint16_t* __restrict__ out)
 {
-    const size_t cells = (size_t)(W + 2) * (H + 2);
+    const size_t cells = (size_t)ftgp_plane256(W, H) * 128;          // 16-bit entries per (padded) plane
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= cells * FTGP_SECTORS) return;
     const int sector = (int)(i / cells);

@@ -78,6 +78,20 @@ FTGP_HD uint32_t ftgp_box_entry(const uint16_t* runx, const uint16_t* runy, int 
     return (uint32_t)kx | ((uint32_t)ky << 8);
 }
 
+// size of one sector plane in units of 256 bytes ((W + 2) x (H + 2) 16-bit entries, padded)
+FTGP_HD uint32_t ftgp_plane256(int W, int H) { return (2u * (uint32_t)(W + 2) * (uint32_t)(H + 2) + 255u) >> 8; }
+
+// Distance to a pixel boundary below which the landing estimate floor(p + d * s) is not trusted and the specification's
+// comparisons decide.  With unit roundoff u = 2^-24 the estimate fl(p + d * s) is off by at most u * M and the specification's
+// crossing time ((float)b - p) * (1 / d) by a relative 3u, i.e. by at most 3u * M pixels (M = largest coordinate); twice that
+// bound, on the next power of two of M:  eps = 2 * 4u * M = 2^-21 * pow2ceil(max(W, H) + 2).
+FTGP_HD float ftgp_snap_eps(int W, int H)
+{
+    const int m = (W > H ? W : H) + 2;
+    int p = 1; while (p < m) p <<= 1;
+    return (float)p * (1.0f / 2097152.0f);
+}
+
 // One ray in the mirrored frame.  mx / my (0 or -1) turn the mirrored cell back into the true pixel (ix ^ mx, iy ^ my);
 // byte offset of its entry = offC + 2 * ((iy ^ my) * fstride + (ix ^ mx)), offC = start of the sector's plane + the ring.
 struct FtgpRay {
@@ -95,25 +109,25 @@ FTGP_HD void ftgp_ray_park(FtgpRay& r, float result)
     r.ix = r.iy = 0; r.offC = 0; r.mx = r.my = 0;
 }
 
-// fstride = W + 2 (cells per plane row), plane_bytes = 2 * (W + 2) * (H + 2)
-FTGP_HD void ftgp_ray_init(FtgpRay& r, float pu, float pv, float du, float dv, int W, int H, int fstride, uint32_t plane_bytes)
+// fstride = W + 2 (cells per plane row); plane256 = bytes per sector plane / 256 (planes are padded to a multiple of 256 B);
+// ivx, ivy = |1 / du|, |1 / dv| correctly rounded (IEEE division; +inf where the direction is 0: that axis is never stepped)
+FTGP_HD void ftgp_ray_init(FtgpRay& r, float pu, float pv, float du, float dv, float ivx, float ivy, int W, int H, int fstride, uint32_t plane256)
 {
     const float fx = floorf(pu), fy = floorf(pv);
     const bool inside = fx >= 0.0f && fx < (float)W && fy >= 0.0f && fy < (float)H;
     const int ix0 = (int)fx, iy0 = (int)fy;
     const bool mx = du < 0.0f, my = dv < 0.0f;
     const float adu = fabsf(du), adv = fabsf(dv);
-    const int dom = adu >= adv ? 0 : 1;
+    const bool ydom = !(adu >= adv);
     r.pum = mx ? -pu : pu; r.pvm = my ? -pv : pv;
     r.dum = adu; r.dvm = adv;
-    r.ivx = fabsf(1.0f / du);          // IEEE division: +inf where the direction is 0 (that axis is never stepped)
-    r.ivy = fabsf(1.0f / dv);
+    r.ivx = ivx; r.ivy = ivy;
     r.s = 0.0f; r.result = -1.0f;
-    int sector = (mx ? 1 : 0) | (my ? 2 : 0) | (dom << 2);
-    if (FTGP_SECTORS == 16) sector |= (2.0f * (dom ? adu : adv) > (dom ? adv : adu)) ? 8 : 0;      // slope minor / major above 1/2
+    uint32_t sector = (mx ? 1u : 0u) | (my ? 2u : 0u) | (ydom ? 4u : 0u);
+    if (FTGP_SECTORS == 16) sector |= (2.0f * (ydom ? adu : adv) > (ydom ? adv : adu)) ? 8u : 0u;      // slope minor / major above 1/2
     r.mx = mx ? -1 : 0; r.my = my ? -1 : 0;
     r.ix = ix0 ^ r.mx; r.iy = iy0 ^ r.my;
-    r.offC = (int)((uint32_t)sector * plane_bytes) + 2 * (fstride + 1);
+    r.offC = (int)(((sector * plane256) << 8) + 2u * (uint32_t)(fstride + 1));
     if (!inside) { r.ix = r.iy = 0; r.offC = 0; r.mx = r.my = 0; }       // starts off the image: ring cell (0, 0), result stays -1
 }
 
@@ -175,8 +189,8 @@ FTGP_HD void ftgp_ray_commit(FtgpRay& r, const FtgpStep& st, int t)
 FTGP_HD float ftgp_march_one(const uint16_t* field, int W, int H, float eps, float pu, float pv, float du, float dv)
 {
     const int fstride = W + 2;
-    const uint32_t plane_bytes = 2u * (uint32_t)fstride * (uint32_t)(H + 2);
-    FtgpRay r; ftgp_ray_init(r, pu, pv, du, dv, W, H, fstride, plane_bytes);
+    const uint32_t plane256 = ftgp_plane256(W, H);
+    FtgpRay r; ftgp_ray_init(r, pu, pv, du, dv, fabsf(1.0f / du), fabsf(1.0f / dv), W, H, fstride, plane256);
     for (int guard = 0; guard < 4 * 8192; ++guard) {
         const uint32_t w = field[ftgp_ray_offset(r, fstride) >> 1];
         FtgpStep st;

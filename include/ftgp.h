@@ -231,6 +231,10 @@ int ftgp_metrics_allgather(FtgpEnv *env, double *out);
 int ftgp_fakelidar(int device_id, const double *dt, int H, int W, int n_origins, const double *origins, int rangefinders,
                    const double *cosines, const double *sines, double eps, double *scan, double *points);
 
+/* Self-test of device arithmetic the kernels rely on (no reference counterpart): the fast reciprocal of the ray set-up against
+ * the IEEE division of the specification over all 2^32 binary32 bit patterns.  *mismatches = number of differing results. */
+int ftgp_selftest(int device_id, int64_t *mismatches);
+
 /* Timing of the most recent ftgp_step / ftgp_rollout launch sequence, measured with HIP events on the handle's stream (ms). */
 int ftgp_last_kernel_ms(FtgpEnv *env, float *ms);
 

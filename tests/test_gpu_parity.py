@@ -42,6 +42,12 @@ def test_library_is_hip_and_device_present(product):
     assert product.fn("device_count")() >= 1
 
 
+def test_device_selftest_fast_reciprocal_is_ieee_division(product):
+    """The ray set-up computes |1/d| with v_rcp_f32 + one fused Newton step; the specification says IEEE division.
+    ftgp_selftest compares the two over all 2^32 binary32 bit patterns on the device."""
+    assert capi.selftest(product) == 0
+
+
 @pytest.mark.parametrize("name", ["track", "circle", "small-circle", "inkscape"])
 @pytest.mark.parametrize("R", [36, 1080])
 def test_lidar_single_sweep_bit_exact(product, oracle, name, R):
@@ -155,6 +161,83 @@ def test_g5_progress_block_on_gpu(product, trace):
     replay_progress_trace(product, trace)
 
 
+def test_g4_accessor_table_on_gpu(product):
+    """Rows a5 / a6: lap_completion / absolute_completion of the reference's truth table (fixture G4) read back through
+    ftgp_get_progress columns 2-3 and ftgp_get_snapshot columns 7-8."""
+    from tests.test_oracle_golden import drive_g4_table
+    drive_g4_table(product)
+
+
+def test_forward_lap_by_driving(product, oracle):
+    """A whole lap driven by the on-device nidc driver (circle, 90 rays, lap_target 1): the forward crossing appends the lap
+    time inside the persistent kernel, `finished` is reached by driving, finished cars get the null driver and their
+    rangefinders are switched off -- GPU vs oracle, uneven launch sizes."""
+    t = load_track("circle")
+    g, o = both(product, oracle, t, n_envs=16, n_rays=90, spawn_mode=1, seed=7, lap_target=1)
+    with g, o:
+        for chunk in (1, 4999, 5000, 3333, 6667):
+            g.rollout("nidc", chunk); o.rollout("nidc", chunk)
+            assert_same_state(g, o)
+        p = g.progress()
+        cnt, times = g.lap_times()
+        fin = p[:, 4] == 1
+        assert fin.sum() >= 8                                          # most cars drive the lap forwards ...
+        assert (p[fin, 0] == 1).all() and (cnt[fin] == 1).all()        # ... laps + 1, one lap time, custom.py:1357-1366
+        assert ((times[fin, 0] > 20) & (times[fin, 0] < 80)).all()     # 83 track units at <= 1.5 units/s
+        assert (p[~fin, 0] < 0).any()                                  # the others lap backwards (negative laps, custom.py:1352-1356)
+        np.testing.assert_array_equal(g.lidar()[fin], 0.0)             # shadow_rangefinders, custom.py:1436-1439
+        np.testing.assert_array_equal(g.ctrl()[fin], 0.0)              # LobotomyDriver, custom.py:1446
+        assert g.lidar()[~fin].any()
+
+
+def test_config4_shard_shape_random_policy(product, oracle):
+    """BASELINE.json configs[3] as one rank sees it: a 4096-env shard at env_base = 7 * 4096 (rank 7 of 8) under the
+    counter-based random policy, against an oracle prefix of the same shard."""
+    t = load_track("track")
+    kw = dict(n_rays=1080, spawn_mode=1, seed=1234, env_base=7 * 4096)
+    with capi.Env(product, t, n_envs=4096, **kw) as g, capi.Env(oracle, t, n_envs=24, **kw) as o:
+        oracle.dll.oracle_set_threads(o.h, 8)
+        g.rollout("random", 120); o.rollout("random", 120)
+        np.testing.assert_array_equal(g.lidar()[:24], o.lidar())
+        np.testing.assert_array_equal(g.progress()[:24], o.progress())
+        np.testing.assert_array_equal(g.ctrl()[:24], o.ctrl())           # same draws: keyed (seed, GLOBAL car index, step)
+        np.testing.assert_allclose(g.pose()[:24], o.pose(), rtol=0, atol=1e-12)
+        with capi.Env(product, t, n_envs=24, n_rays=1080, spawn_mode=1, seed=1234) as g0:
+            g0.rollout("random", 120)
+            assert (g0.ctrl() != g.ctrl()[:24]).any()                   # a different shard draws different controls
+
+
+def test_bubble_wrap_softeners(product, oracle):
+    """f-3: option bubble_wrap (custom.py:1041-1055) adds the four wheel softeners to the wall-contact set; naive_flatten
+    (custom.py:1338-1339) is accepted and changes nothing on a planar model."""
+    t = load_track("track")
+    kw = dict(n_envs=64, n_rays=90, spawn_mode=1, seed=11)
+    g, o = both(product, oracle, t, bubble_wrap=True, **kw)
+    with g, o, capi.Env(product, t, **kw) as plain, capi.Env(product, t, naive_flatten=True, **kw) as flat:
+        for e in (g, o, plain, flat):
+            e.rollout("random", 1500)                                  # random controls: plenty of wall contacts
+        assert_same_state(g, o)
+        assert (np.abs(g.pose() - plain.pose()) > 1e-6).any()          # the softeners did touch something
+        np.testing.assert_array_equal(flat.pose(), plain.pose())
+        np.testing.assert_array_equal(flat.lidar(), plain.lidar())
+
+
+def test_enlarged_vehicle_box_is_seen(product, oracle):
+    """The conservative cull before the inter-vehicle ray tests derives its radius from the vehicle's own extents: a car
+    with a chassis box three times the default must still be seen exactly as the oracle sees it."""
+    t = load_track("track")
+    v = product.default_vehicle()
+    v.box_xmin, v.box_xmax, v.box_ymin, v.box_ymax = -0.31, 0.31, -0.14, 0.14
+    kw = dict(n_envs=12, cars_per_env=4, n_rays=1080, spawn_mode=0, lap_target=3, vehicle=v)
+    g, o = both(product, oracle, t, **kw)
+    with g, o, capi.Env(oracle, t, **dict(kw, vehicle=None)) as small:
+        g.step(1); o.step(1); small.step(1)
+        np.testing.assert_array_equal(g.lidar(), o.lidar())
+        assert (g.lidar() != small.lidar()).any()
+        g.rollout("fast", 200); o.rollout("fast", 200)
+        assert_same_state(g, o)
+
+
 def test_multi_car_env_config5(product, oracle):
     """Config 5: 4 cars per env share a world -- inter-vehicle rays and car-car contact."""
     t = load_track("track")
@@ -257,7 +340,7 @@ def test_rccl_communicator_single_rank(product):
         assert rec[0][0] == 8 * 40 and rec[0][1] == 8
 
 
-@pytest.mark.parametrize("name", ["track", "small-circle"])
+@pytest.mark.parametrize("name", ["track", "circle", "small-circle", "inkscape"])
 def test_g2_fakelidar_on_gpu_bit_exact(product, name):
     """Row a3: the fakelidar-compat kernel against the outputs of the reference's own raycast.fakelidar (fixture G2)."""
     from scipy.ndimage import distance_transform_edt
@@ -309,9 +392,7 @@ def test_finished_cars_become_ghosts(product, oracle):
         g.rollout("fast", 50); o.rollout("fast", 50)
         assert_same_state(g, o)
         np.testing.assert_array_equal(g.ctrl(), 0.0)
-        # nobody sees anybody: identical to single-car worlds spawned at the same offsets
-        r = g.lidar().reshape(6, 3, 90)
-        np.testing.assert_array_equal(r[0], r[1])
+        np.testing.assert_array_equal(g.lidar(), 0.0)               # their own rangefinders are switched off (custom.py:1436-1439)
 
 
 def test_workgroup_shape_does_not_change_a_bit(product, oracle, monkeypatch):

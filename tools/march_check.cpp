@@ -37,7 +37,7 @@ int main(int argc, char** argv)
     // the shipped host tables + the shipped per-cell box search (ftgp_box_entry, the body of ftgp_box_field_kernel) on the CPU
     HostTables g; build_tables(t, 3, g);
     const int W = t.width, H = t.height;
-    const size_t cells = (size_t)(W + 2) * (H + 2);
+    const size_t cells = (size_t)ftgp_plane256(W, H) * 128;
     std::vector<uint16_t> field(cells * FTGP_SECTORS, (uint16_t)FTGP_FIELD_OUT);
     long gw_bad = 0;
     for (int oct = 0; oct < FTGP_SECTORS; ++oct)
@@ -48,7 +48,7 @@ int main(int argc, char** argv)
                 if ((e == 0) != wall_at(t, x, y) || (e != 0 && (e & 255u) == 0)) ++gw_bad;      // 0 <=> wall; a free cell never carries kx = 0
             }
     printf("grid_wall: %ld mismatching pixels\n", gw_bad);
-    const float eps = 1.0f / 512.0f;
+    const float eps = ftgp_snap_eps(W, H);
     std::mt19937_64 rng(seed);
     std::uniform_real_distribution<double> ux(0, t.width), uy(0, t.height), ua(0, 2 * M_PI), u01(0, 1);
     long bad = 0, hits = 0;

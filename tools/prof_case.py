@@ -6,7 +6,7 @@ from ft_grandprix_amd import capi
 from ft_grandprix_amd.track import load_track
 n_envs, n_rays, policy, steps = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4])
 cars = int(sys.argv[5]) if len(sys.argv) > 5 else 1
-lib = capi.load()
+lib = capi.CLib(os.environ["FTGP_LIB"], "ftgp_") if os.environ.get("FTGP_LIB") else capi.load()
 with capi.Env(lib, load_track("track"), n_envs=n_envs, cars_per_env=cars, n_rays=n_rays, spawn_mode=1, seed=1234) as e:
     e.rollout(policy, 100)
     e.rollout(policy, steps)

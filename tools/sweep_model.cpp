@@ -52,11 +52,11 @@ int main(int argc, char** argv)
     const int R = atoi(argv[3]), cpb = atoi(argv[4]), wpb = atoi(argv[5]), refill = atoi(argv[6]);
     const float eps = ldexpf(1.0f, -(argc > 7 ? atoi(argv[7]) : 9));
     Tables g; build(bits, W, H, wpr, g);
-    const size_t cells = (size_t)(W + 2) * (H + 2);
+    const size_t cells = (size_t)ftgp_plane256(W, H) * 128;
     std::vector<uint16_t> field(cells * FTGP_SECTORS, (uint16_t)FTGP_FIELD_OUT);
     for (int oct = 0; oct < FTGP_SECTORS; ++oct) for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x)
         field[(size_t)oct * cells + (size_t)(y + 1) * (W + 2) + (x + 1)] = (uint16_t)BOX_ENTRY(g.runx.data(), g.runy.data(), W, H, x, y, oct);
-    const int fstride = W + 2; const uint32_t plane_bytes = 2u * (uint32_t)fstride * (uint32_t)(H + 2);
+    const int fstride = W + 2; const uint32_t plane256 = ftgp_plane256(W, H);
     std::vector<float> bx(R), by(R);
     for (int j = 0; j < R; ++j) { const double phi = ((360.0 / R) * j - 90.0) * (M_PI / 180.0); bx[j] = (float)sin(phi); by[j] = (float)(-cos(phi)); }
     const float isx = (float)(1.0 / ph[1]), isy = (float)(1.0 / ph[2]), r0 = 0.03f;
@@ -89,7 +89,7 @@ int main(int argc, char** argv)
                             const float chf = (float)ch, shf = (float)sh;
                             const float dxw = fmaf(chf, bx[j], -(shf * by[j])), dyw = fmaf(shf, bx[j], chf * by[j]);
                             const float du = dxw * isx, dv = -(dyw * isy);
-                            ftgp_ray_init(l.r, fmaf(du, -r0, u0), fmaf(dv, -r0, v0), du, dv, W, H, fstride, plane_bytes);
+                            ftgp_ray_init(l.r, fmaf(du, -r0, u0), fmaf(dv, -r0, v0), du, dv, fabsf(1.0f / du), fabsf(1.0f / dv), W, H, fstride, plane256);
                             l.done = false;
                         }
                     }
