@@ -3,58 +3,71 @@
 
 A "step" is one pass of the hot path over the whole batch: driver (fast, on device) -> LiDAR sweep written
 to HBM -> integrate -> lap progress, for every env.  All inputs are resident in HBM before the timed region;
-the K timed steps run as ONE persistent launch (the state stays in registers between steps).
+the K timed steps run as ONE persistent launch (the state stays in LDS between steps).
 
-    python bench.py --gpus N --steps K --warmup W        # N > 1: launched by torch.distributed.run, one rank per GPU
+    python bench.py --gpus N --steps K --warmup W
 
-Envs shard across ranks with no data-path collective (weak scaling: 4096 envs per GPU); the only exchange is the
-end-of-launch metrics all-gather over RCCL, issued on a side stream.  Rank 0 prints ONE JSON line.
+N > 1: one process per GPU.  Launched by `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py
+--gpus N` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the env), or, when no launcher set WORLD_SIZE, bench.py starts
+its own N ranks.  The host path is torch-free: rendezvous, barrier and the max-over-ranks timing go over
+ft_grandprix_amd.dist.Rendezvous (TCP on MASTER_ADDR); envs shard across ranks with no data-path collective (weak scaling:
+4096 envs per GPU); the only exchange is the end-of-launch metrics all-gather over RCCL, issued on a side stream.
+Rank 0 prints ONE JSON line.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from ft_grandprix_amd import capi  # noqa: E402
+from ft_grandprix_amd import dist as ftdist  # noqa: E402
 from ft_grandprix_amd.track import load_track  # noqa: E402
 
 ALGO_BYTES_PER_ENV_STEP = lambda n_rays, cars: cars * (4 * n_rays + 832)   # SURVEY.md 8d: 5152 B at R = 1080
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_MEASURED_COPY_GBS = 6290.0
+N_SIMD = 256 * 4               # MI355X: 256 CUs x 4 SIMD-32; a wave64 VALU instruction issues over 2 cycles on one SIMD
+PROFILE_DIR = os.path.join(ROOT, "profiles", "round2")
 
 
-def measured_traffic(n_envs, n_rays, cars, policy, steps):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (tools/traffic.sh: FETCH_SIZE and WRITE_SIZE in
-    separate runs, KB -> bytes; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  The counters cannot
-    be read from inside this process, so the per-env-step figure of the same configuration is scaled to this launch."""
-    p = os.path.join(ROOT, "profiles", "traffic_latest.json")
+def kernel_source_sha():
+    """Identity of the kernel sources a committed counter file was measured on."""
+    h = hashlib.sha256()
+    for rel in ("ft_grandprix_amd/csrc/ftgp_kernels.hip", "ft_grandprix_amd/csrc/ftgp_march.h", "ft_grandprix_amd/csrc/ftgp_device.h",
+                "ft_grandprix_amd/csrc/ftgp_api.hip", "include/ftgp.h"):
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def committed_counters(name, n_envs, n_rays, cars, policy):
+    """A counter summary committed under profiles/round2 by tools/collect_profile.py (rocprofv3 --pmc, separate passes), if it
+    was measured on this configuration.  The counters cannot be read from inside this process; `stale` says whether the
+    kernel sources have changed since."""
+    p = os.path.join(PROFILE_DIR, name)
     if not os.path.exists(p):
         return None
     t = json.load(open(p))
     if (t.get("n_envs"), t.get("n_rays", 1080), t.get("cars", 1), t.get("policy", "fast")) != (n_envs, n_rays, cars, policy):
         return None
-    return t["traffic_bytes_per_env_step"] * n_envs * steps
-
-
-def _try(fn):
-    try:
-        fn()
-        return None
-    except Exception as exc:      # noqa: BLE001 - reported by the caller
-        return exc
+    t["stale"] = t.get("kernel_source_sha") != kernel_source_sha()
+    return t
 
 
 def cpu_baseline(track, n_rays, policy, cars, seed):
     """The CPU oracle ("port") on a bounded sample of the same workload, on this host's cores (rank 0, N = 1 only)."""
     from tests.helpers import load_oracle
     ora = load_oracle()
-    threads = max(1, min(os.cpu_count() or 1, int(os.environ.get("FTGP_CPU_THREADS", "16"))))
+    host_cpus = os.cpu_count() or 1
+    threads = max(1, min(host_cpus, int(os.environ.get("FTGP_CPU_THREADS", "16"))))
     threads = min(threads, ora.dll.oracle_max_threads()) if threads > 1 else 1
     n_envs = 64 * threads
     with capi.Env(ora, track, n_envs=n_envs, cars_per_env=cars, n_rays=n_rays, spawn_mode=1, seed=seed) as o:
@@ -66,9 +79,30 @@ def cpu_baseline(track, n_rays, policy, cars, seed):
         t0 = time.perf_counter()
         o.rollout(policy, steps)
         dt = time.perf_counter() - t0
-    return {"value": n_envs * steps / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
+    return {"value": n_envs * steps / dt, "unit": "env-steps/s", "cores": threads, "host_cpus": host_cpus, "kind": "port",
             "sample": f"{n_envs} envs x {steps} steps of the same workload (first {n_envs} envs of the batch), "
-                      f"oracle/ftgp_oracle.c with OpenMP over envs, {dt:.1f} s"}
+                      f"oracle/ftgp_oracle.c with OpenMP over envs on {threads} of the host's {host_cpus} logical CPUs, {dt:.1f} s"}
+
+
+def launch_ranks(n, argv):
+    """No launcher set WORLD_SIZE: start the N ranks ourselves (one child per GPU) and return the worst exit code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   FTGP_JOB_TOKEN=f"bench-{os.getpid()}")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rcs = []
+    try:
+        for p in procs:
+            rcs.append(p.wait())
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return max(abs(rc) for rc in rcs)
 
 
 def main():
@@ -85,65 +119,67 @@ def main():
     ap.add_argument("--repeats", type=int, default=1, help="timed launches of K steps (the best is reported in ms_per_step_best)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))        # never fall through to a 1-rank run
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with `python -m torch.distributed.run --nnodes=1 "
+                         f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port P bench.py --gpus {args.gpus} ...`")
 
-    dist = None
-    if world > 1:
-        import torch.distributed as dist   # rendezvous / barrier plumbing only; the data path is HIP + RCCL
-        dist.init_process_group(backend="gloo")
-
+    rdzv = ftdist.Rendezvous.from_env() if world > 1 else None
     lib = capi.load()
-    if lib.fn("device_count")() < 1:
+    n_dev = lib.fn("device_count")()
+    if n_dev < 1:
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
     track = load_track(args.track)
     seed = 1234
     # rank r owns envs [r * envs_per_gpu, (r + 1) * envs_per_gpu) of one world-sized batch (BASELINE.json configs[3] at N = 8)
-    n_dev = lib.fn("device_count")()
     env = capi.Env(lib, track, n_envs=args.envs_per_gpu, cars_per_env=args.cars, n_rays=args.rays, spawn_mode=1,
                    seed=seed, device_id=local_rank % n_dev, env_base=rank * args.envs_per_gpu)
     collective = "none (1 rank)"
-    gloo_gather = None
+    host_gather = False
     if world > 1:
-        import torch
-        from ft_grandprix_amd import dist as ftdist
-        collective = "rccl ncclAllGather (xGMI), side stream"
-        ok = 1
-        try:
-            if world > n_dev:
-                raise RuntimeError("more ranks than GPUs: RCCL refuses two ranks on one device")
-            if os.environ.get("FTGP_BENCH_COLLECTIVE", "rccl") != "rccl":
-                raise RuntimeError("FTGP_BENCH_COLLECTIVE requests the gloo gather")
-            uid = [capi.comm_unique_id(lib) if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0)
-            # watchdog: a stalled RCCL bootstrap must not hang the scaling run
-            import threading
-            box = {}
-            th = threading.Thread(target=lambda: box.setdefault("err", _try(lambda: env.comm_init(uid[0], rank, world))), daemon=True)
-            th.start(); th.join(timeout=float(os.environ.get("FTGP_RCCL_INIT_TIMEOUT", "180")))
-            if th.is_alive():
-                raise RuntimeError("ncclCommInitRank did not return in time")
-            if box.get("err") is not None:
-                raise box["err"]
-        except Exception as exc:   # rehearsal on a box with fewer GPUs than ranks, or an RCCL problem: keep going over gloo, and say so
-            ok = 0
-            print(f"[rank {rank}] RCCL communicator not used ({exc}); metrics go over the gloo gather", file=sys.stderr)
-        flag = torch.tensor([ok]); dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag[0]) == 0:
-            gloo_gather = ftdist.GlooGather()
-            collective = "gloo all_gather (RCCL communicator not used, see stderr)"
+        want = os.environ.get("FTGP_BENCH_COLLECTIVE", "rccl")
+        if want == "host":            # explicit rehearsal mode (e.g. more ranks than GPUs on one box): labelled as such
+            host_gather = True
+            collective = "host TCP gather (FTGP_BENCH_COLLECTIVE=host; RCCL not requested)"
+        else:
+            collective = "rccl ncclAllGather (xGMI), side stream"
+            err = None
+            try:
+                uid = ftdist.exchange_unique_id(rdzv, lambda: capi.comm_unique_id(lib))   # symmetric: a rank-0 failure reaches every rank
+                box = {}
+                def init():
+                    try:
+                        env.comm_init(uid, rank, world)
+                    except Exception as exc:      # noqa: BLE001 - reported below
+                        box["err"] = exc
+                th = threading.Thread(target=init, daemon=True)   # watchdog: a stalled RCCL bootstrap must not hang the scaling run
+                th.start(); th.join(timeout=float(os.environ.get("FTGP_RCCL_INIT_TIMEOUT", "180")))
+                if th.is_alive():
+                    err = "ncclCommInitRank did not return in time"
+                elif "err" in box:
+                    err = str(box["err"])
+            except Exception as exc:              # noqa: BLE001
+                err = str(exc)
+            oks = rdzv.allgather_bytes(b"\x01" if err is None else b"\x00" + err.encode()[:300])
+            bad = [(r, o[1:].decode(errors="replace")) for r, o in enumerate(oks) if o[:1] != b"\x01"]
+            if bad:                   # RCCL was requested and is not usable: fail loudly on every rank, no silent fallback
+                if rank == 0:
+                    print(f"bench.py: the RCCL communicator could not be set up: {bad}", file=sys.stderr)
+                rdzv.close()
+                os._exit(3)           # a stalled RCCL thread may still hold the handle: do not wait for it
 
     def gather():
-        if gloo_gather is not None:
-            return gloo_gather.all_gather(env.metrics_local())
+        if host_gather:
+            return rdzv.all_gather(env.metrics_local())
         return env.metrics_allgather()
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
+        if rdzv is not None:
+            rdzv.barrier()
 
     # warmup (untimed)
     env.rollout(args.policy, args.warmup)
@@ -161,20 +197,38 @@ def main():
     barrier()
     wall = (time.perf_counter() - t0) / args.repeats
     kernel_ms = kms if args.repeats == 1 else best_ms
-
-    if dist is not None:
-        import torch
-        tmax = torch.tensor([wall, kernel_ms / 1e3], dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        wall, kernel_s = float(tmax[0]), float(tmax[1])
-    else:
-        kernel_s = kernel_ms / 1e3
+    if rdzv is not None:
+        wall, kernel_ms = [float(x) for x in rdzv.max([wall, kernel_ms])]     # max over ranks
+    kernel_s = kernel_ms / 1e3
 
     if rank == 0:
         total_envs = args.envs_per_gpu * world
         value = total_envs * args.steps / wall
         bytes_per_launch = ALGO_BYTES_PER_ENV_STEP(args.rays, args.cars) * args.envs_per_gpu * args.steps
         achieved = bytes_per_launch / kernel_s / 1e9
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None, "kernel": env.kernel_name(), "kernel_ms_per_launch": kernel_s * 1e3,
+                "algorithmic_bytes_per_launch": bytes_per_launch, "frac_of_measured_copy_6290": achieved / HBM_MEASURED_COPY_GBS,
+                "rays_per_s": args.envs_per_gpu * args.cars * args.rays * args.steps / kernel_s,
+                "limiter": "valu-issue (see `valu`): the path sits above the HBM ridge, SURVEY.md 7.5"}
+        tr = committed_counters("traffic_latest.json", args.envs_per_gpu, args.rays, args.cars, args.policy)
+        if tr is not None:
+            # HBM bytes per launch = the committed PMC figure per env-step (FETCH_SIZE x2 + WRITE_SIZE, separate passes) scaled to this launch
+            roof["traffic"] = tr["traffic_bytes_per_env_step"] * args.envs_per_gpu * args.steps
+            roof["traffic_source"] = {"file": "profiles/round2/traffic_latest.json", "measured_in_this_run": False,
+                                      "kernel_source_sha": tr.get("kernel_source_sha"), "stale": tr["stale"],
+                                      "bytes_per_env_step": tr["traffic_bytes_per_env_step"]}
+        sq = committed_counters("sq_latest.json", args.envs_per_gpu, args.rays, args.cars, args.policy)
+        if sq is not None:
+            c, steps_c = sq["counters"], sq["steps"]
+            valu_per_car_step = c["SQ_INSTS_VALU"] / (sq["n_envs"] * sq.get("cars", 1) * steps_c)
+            cycles = c["GRBM_GUI_ACTIVE"] / 8.0                         # the counter sums the 8 XCDs
+            roof["valu"] = {"insts_per_car_step": valu_per_car_step,
+                            "issue_frac": c["SQ_INSTS_VALU"] * 2.0 / (N_SIMD * cycles),      # of one wave64 VALU op per 2 cycles per SIMD
+                            "busy_frac": c["SQ_ACTIVE_INST_VALU"] * 4.0 / (N_SIMD * cycles),  # SQ_ACTIVE_INST_VALU counts quad-cycles per wave
+                            "shader_clock_ghz": cycles / (sq["kernel_ms"] * 1e6) if sq.get("kernel_ms") else None,
+                            "source": {"file": "profiles/round2/sq_latest.json", "measured_in_this_run": False,
+                                       "kernel_source_sha": sq.get("kernel_source_sha"), "stale": sq["stale"]}}
         out = {
             "metric": "env-steps/sec (4096 envs, 1080-ray LiDAR) at 1/2/4/8 MI355X; HBM roofline %",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -184,24 +238,16 @@ def main():
                                    f"{args.rays}-ray LiDAR, {args.policy} driver on device (BASELINE.json configs[2])",
                        "envs_per_gpu": args.envs_per_gpu, "n_rays": args.rays, "cars_per_env": args.cars,
                        "policy": args.policy, "steps_per_launch": args.steps, "parallelism": f"env-shard x{world}"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic(args.envs_per_gpu, args.rays, args.cars, args.policy, args.steps),
-                         "kernel": env.kernel_name(), "kernel_ms_per_launch": kernel_s * 1e3,
-                         "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "frac_of_measured_copy_6290": achieved / HBM_MEASURED_COPY_GBS,
-                         "rays_per_s": args.envs_per_gpu * args.cars * args.rays * args.steps / kernel_s},
+            "roofline": roof,
             "metrics_allgather": {"collective": collective, "ranks": int(metrics.shape[0]), "sum_laps": float(metrics[:, 2].sum()),
                                   "sum_steps": float(metrics[:, 0].sum())},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(track, args.rays, args.policy, args.cars, seed)
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
-    if gloo_gather is not None and world <= n_dev:
-        os._exit(0)            # a stalled RCCL thread may still hold the handle: do not wait for it
+    if rdzv is not None:
+        rdzv.barrier()
+        rdzv.close()
     env.close()
 
 

@@ -165,6 +165,7 @@ int lds_layout(DeviceParams& P, int cpb, int wpb)
     P.off_scan = o;   o += 2 * cpb * P.win_floats * (int)sizeof(float);   // double-buffered by step parity
     P.off_list = o;   o += wpb * FTGP_WAVE * (int)sizeof(int);
     P.off_pool = o;   o += 16;
+    P.off_k1 = o;     o += FTGP_MAX_CARS_PER_BLOCK * (FTGP_FORCE_TERMS * 24 + 4 * 8 + 104);      // K1 staging: force terms | new wheel spins | new state
     P.lds_bytes = o;
     P.cars_per_block = cpb; P.waves_per_block = wpb;
     return o;

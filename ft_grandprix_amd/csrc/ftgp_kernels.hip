@@ -23,6 +23,12 @@
 // says "fma"), so results are bit-identical to the CPU oracle.
 #include "ftgp_device.h"
 
+// K1 staging types
+struct Force { double fx, fy, tz; };
+struct Dyn { double x, y, qw, qz, vx, vy, wz, qs, qsd, w[4]; };
+static_assert(sizeof(Dyn) == 104 && offsetof(CarCore, w) == offsetof(Dyn, w) && offsetof(CarCore, qsd) == offsetof(Dyn, qsd), "Dyn must mirror the head of CarCore");
+#define FTGP_FORCE_TERMS 11      // 4 wheels, 3 chassis circles, 4 softeners: summed in this order
+
 struct Lds {
     const VehLds* veh;
     const double* path;
@@ -33,6 +39,9 @@ struct Lds {
     float* scan;              // [2][cars_per_block][win_floats]: ranges[0] | ranges[eighth : n - eighth], double-buffered by step parity
     int* list;                // [waves_per_block][64] driver scratch
     int* pool;                // [2] next ray of the sweep, [2] drivers finished -- both double-buffered by step parity
+    Force* terms;             // [cars_per_block][FTGP_FORCE_TERMS] K1 staging: force terms in the order they are summed
+    double* wnew;             // [cars_per_block][4] K1 staging: new wheel spins
+    Dyn* next;                // [cars_per_block] K1 staging: new dynamic state before the commit
 };
 
 // A wave-uniform value the optimiser cannot see through.  The step loop rebuilds its LDS pointers from such offsets every
@@ -40,13 +49,14 @@ struct Lds {
 // would stay live across the sweep and end up in scratch memory under the 64-VGPR budget.
 __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+s"(v)); return v; }
 
-struct LdsOffsets { int params, veh, path, ray, cars, frame, steps, scan, list, pool; };
+struct LdsOffsets { int params, veh, path, ray, cars, frame, steps, scan, list, pool, k1; };
 
 __device__ __forceinline__ LdsOffsets lds_offsets(const DeviceParams& P)
 {
     LdsOffsets o;
     o.params = sgpr(P.off_params); o.veh = sgpr(P.off_veh); o.path = sgpr(P.off_path); o.ray = sgpr(P.off_ray); o.cars = sgpr(P.off_cars);
     o.frame = sgpr(P.off_frame); o.steps = sgpr(P.off_steps); o.scan = sgpr(P.off_scan); o.list = sgpr(P.off_list); o.pool = sgpr(P.off_pool);
+    o.k1 = sgpr(P.off_k1);
     return o;
 }
 
@@ -62,6 +72,10 @@ __device__ __forceinline__ Lds lds_view(const LdsOffsets& o, unsigned char* lds)
     L.scan = reinterpret_cast<float*>(lds + opaque(o.scan));
     L.list = reinterpret_cast<int*>(lds + opaque(o.list));
     L.pool = reinterpret_cast<int*>(lds + opaque(o.pool));
+    unsigned char* k1 = lds + opaque(o.k1);     // one block: terms | wnew | next (sizes follow from cars_per_block)
+    L.terms = reinterpret_cast<Force*>(k1);
+    L.wnew = reinterpret_cast<double*>(k1 + FTGP_MAX_CARS_PER_BLOCK * FTGP_FORCE_TERMS * sizeof(Force));
+    L.next = reinterpret_cast<Dyn*>(k1 + FTGP_MAX_CARS_PER_BLOCK * (FTGP_FORCE_TERMS * sizeof(Force) + 4 * sizeof(double)));
     return L;
 }
 
@@ -312,9 +326,6 @@ __device__ __forceinline__ void race_store(const Race& r, CarCore* st)
 // =============================================================================================
 // K1: integrate one dt (reduced planar model of template/mushr.em.xml stepped by mj_step, custom.py:1425)
 // =============================================================================================
-struct Force { double fx, fy, tz; };
-struct Dyn { double x, y, qw, qz, vx, vy, wz, qs, qsd, w[4]; };
-static_assert(sizeof(Dyn) == 104 && offsetof(CarCore, w) == offsetof(Dyn, w) && offsetof(CarCore, qsd) == offsetof(Dyn, qsd), "Dyn must mirror the head of CarCore");
 
 // 32 wall bits of bitmap row `row` starting at column x0 (bit i = column x0 + i; columns outside the image read 0)
 __device__ __forceinline__ uint32_t wall_window(const uint32_t* __restrict__ row, int wpr, int x0)
@@ -325,20 +336,22 @@ __device__ __forceinline__ uint32_t wall_window(const uint32_t* __restrict__ row
     return sh ? ((lo >> sh) | (hi << (32 - sh))) : lo;
 }
 
-// One circle (body-frame centre rotated to (rxw, ryw), radius r) against the wall pixels: the deepest penetration wins,
-// ties go to the first pixel in raster order; penalty spring/damper along the contact normal.
-__device__ __forceinline__ void wall_circle(const DeviceParams& P, const uint32_t* __restrict__ bits, const uint32_t* __restrict__ nearbits,
-                                            double sx_, double sy_, double vx, double vy, double wz, double rxw, double ryw, double r,
-                                            double stiffness, double damping, Force& f)
+// One circle (centre = car position + (rxw, ryw), radius r) against the wall pixels: the deepest penetration wins,
+// ties go to the first pixel in raster order; penalty spring/damper along the contact normal.  Returns the force term
+// (zero when nothing is touched).
+__device__ __forceinline__ Force wall_circle(const DeviceParams& P, const uint32_t* __restrict__ bits, const uint32_t* __restrict__ nearbits,
+                                             double sx_, double sy_, double vx, double vy, double wz, double rxw, double ryw, double r,
+                                             double stiffness, double damping)
 {
+    Force out = { 0.0, 0.0, 0.0 };
     const int W = P.width, H = P.height, wpr = P.words_per_row;
     const double sx = P.px_size_x, sy = P.px_size_y;
     const int nx = (int)ceil(r * P.inv_px_x), ny = (int)ceil(r * P.inv_px_y);
     const double px = sx_ + rxw, py = sy_ + ryw;
     const double u = (px - P.origin_x) * P.inv_px_x, w = (P.origin_y - py) * P.inv_px_y;
     const int ix = (int)floor(u), iy = (int)floor(w);
-    if (ix < 0 || ix >= W || iy < 0 || iy >= H) return;
-    if (!((nearbits[(size_t)iy * wpr + (ix >> 5)] >> (ix & 31)) & 1u)) return;      // no wall pixel within the window
+    if (ix < 0 || ix >= W || iy < 0 || iy >= H) return out;
+    if (!((nearbits[(size_t)iy * wpr + (ix >> 5)] >> (ix & 31)) & 1u)) return out;      // no wall pixel within the window
     double best = 0.0; int bcx = 0, bcy = 0; bool found = false;
     const int wx = 2 * nx + 1;
     for (int dy = -ny; dy <= ny; ++dy) {
@@ -364,7 +377,7 @@ __device__ __forceinline__ void wall_circle(const DeviceParams& P, const uint32_
             }
         }
     }
-    if (!found) return;
+    if (!found) return out;
     const double x0w = P.origin_x + (double)bcx * sx, x1w = x0w + sx;
     const double y1w = P.origin_y - (double)bcy * sy, y0w = y1w - sy;
     const double qx = px < x0w ? x0w : (px > x1w ? x1w : px);
@@ -381,16 +394,17 @@ __device__ __forceinline__ void wall_circle(const DeviceParams& P, const uint32_
     const double vcx = vx - wz * ryw, vcy = vy + wz * rxw;
     const double vn = vcx * nxv + vcy * nyv;
     const double mag = stiffness * best - damping * vn;
-    if (mag <= 0.0) return;
-    const double fx = mag * nxv, fy = mag * nyv;
-    f.fx += fx; f.fy += fy; f.tz += rxw * fy - ryw * fx;
+    if (mag <= 0.0) return out;
+    out.fx = mag * nxv; out.fy = mag * nyv; out.tz = rxw * out.fy - ryw * out.fx;
+    return out;
 }
 
 // Circles of this car against the circles of the other cars of the env (penalty spring/damper, pre-step states).
-__device__ __forceinline__ void car_contact(const DeviceParams& P, const FtgpVehicle& v, const Dyn& s, double ch, double sh,
+__device__ __forceinline__ void car_contact(const DeviceParams& P, const FtgpVehicle& v, const CarCore* me, double ch, double sh,
                                             const CarCore* env_cars, int my_slot, Force& f)
 {
     const double r2 = 2.0 * v.contact_radius;
+    const double sx_ = me->x, sy_ = me->y, svx = me->vx, svy = me->vy, swz = me->wz;
     for (int k = 0; k < P.cars_per_env; ++k) {
         if (k == my_slot || env_cars[k].finished) continue;
         const CarCore* b = env_cars + k;
@@ -398,8 +412,8 @@ __device__ __forceinline__ void car_contact(const DeviceParams& P, const FtgpVeh
         const double cb = 1.0 - 2.0 * (bqz * bqz), sb = 2.0 * (bqw * bqz);
         for (int i = 0; i < 3; ++i) {
             const double rxw = ch * v.contact_x[i], ryw = sh * v.contact_x[i];
-            const double px = s.x + rxw, py = s.y + ryw;
-            const double vax = s.vx - s.wz * ryw, vay = s.vy + s.wz * rxw;
+            const double px = sx_ + rxw, py = sy_ + ryw;
+            const double vax = svx - swz * ryw, vay = svy + swz * rxw;
             for (int j = 0; j < 3; ++j) {
                 const double sxw = cb * v.contact_x[j], syw = sb * v.contact_x[j];
                 const double qx = bx + sxw, qy = by + syw;
@@ -435,111 +449,118 @@ __device__ __forceinline__ void frame_write(const DeviceParams& P, const FtgpVeh
     fr->finished = finished;
 }
 
-// K1 + K3 for every car of the workgroup by ONE wave: K1 with one car per lane (all lanes read the pre-step states before
-// any lane commits, so multi-car envs need no staging buffer), then K3 with four lanes per car (25 centre-line points
-// each, first minimum wins).  steps += 1 happens between the two, as in custom.py:1425-1426 followed by the head of the
-// next loop iteration.
+// K1 + K3 for every car of the workgroup by ONE wave, four lanes per car (lane = 4 * car + r).
+//   K1  lane r evaluates wheel r (fl, fr, bl, br), then wall-contact circle r (r < 3), then wheel softener r (bubble_wrap);
+//       the force terms go to an LDS staging row and lane 0 of the car adds them up in the specification's order
+//       (wheels 0..3, circles 0..2, softeners 0..3 -- a term that touches nothing is +0 and changes nothing, because the
+//       running sum starts at +0 and can never become -0), adds the car-car contacts and integrates.  All lanes read the
+//       pre-step states before any lane commits, so multi-car envs need no staging buffer for the states.
+//   K3  25 centre-line points per lane, first minimum wins; steps += 1 happens between K1 and K3, as in custom.py:1425-1426
+//       followed by the head of the next loop iteration.
+// Then the LiDAR frames of the next step are written.
 template <bool MULTI>
 __device__ __forceinline__ void dynamics_lanes(const DeviceParams& P, const Lds& L, LidarFrame* next_frames, int ncars_here, int ci0)
 {
     const int lane = lane_id();
-    const bool on = lane < ncars_here;
-    CarCore* st = L.cars + (on ? lane : 0);
-    Dyn o;
-    if (on) {
-        const FtgpVehicle& v = L.veh->v;
-        const double dt = P.dt;
-        Dyn s;
-        s.x = st->x; s.y = st->y; s.qw = st->qw; s.qz = st->qz; s.vx = st->vx; s.vy = st->vy; s.wz = st->wz;
-        s.qs = st->qs; s.qsd = st->qsd; s.w[0] = st->w[0]; s.w[1] = st->w[1]; s.w[2] = st->w[2]; s.w[3] = st->w[3];
-        const double u_speed = st->u_speed, u_steer = st->u_steer;
-        const bool finished = st->finished != 0;
-        const double ch = 1.0 - 2.0 * (s.qz * s.qz), sh = 2.0 * (s.qw * s.qz);
-        // Ackermann coupling, mushr.em.xml:185-186
-        const double q = s.qs;
-        const double dfl = q * (1.0 + q * (0.375 + q * (0.140625 + q * -0.0722656)));
-        const double dfr = q * (1.0 + q * (-0.375 + q * (0.140625 + q * 0.0722656)));
+    const int c = lane >> 2, r = lane & 3;
+    const bool on = c < ncars_here;
+    CarCore* st = L.cars + (on ? c : 0);
+    Force* terms = L.terms + (on ? c : 0) * FTGP_FORCE_TERMS;
+    const FtgpVehicle& v = L.veh->v;
+    const double dt = P.dt;
+    const bool finished = st->finished != 0;
+    const double qw = st->qw, qz = st->qz;
+    const double ch = 1.0 - 2.0 * (qz * qz), sh = 2.0 * (qw * qz);
+    {   // ---- wheel r
+        const double vx = st->vx, vy = st->vy, wz = st->wz;
+        // Ackermann coupling, mushr.em.xml:185-186: q + 0.375 q^2 + 0.140625 q^3 - 0.0722656 q^4 (fl), the odd signs flipped for fr
+        const double q = st->qs;
+        const double c1 = (r == 0) ? 0.375 : -0.375, c3 = (r == 0) ? -0.0722656 : 0.0722656;
+        const double steer = q * (1.0 + q * (c1 + q * (0.140625 + q * c3)));
+        const double ang = (r < 2) ? steer : 0.0;                       // the rear wheels do not steer: the polynomials give exactly (1, 0) at 0
+        const double cwi = spec_cos(ang), swi = spec_sin(ang);
         // velocity servo on the tendon = mean wheel spin, mushr.em.xml:180,191-196
-        const double wbar = 0.25 * (((s.w[0] + s.w[1]) + s.w[2]) + s.w[3]);
-        double fa = v.throttle_kv * (u_speed - v.throttle_gear * wbar);
+        const double wbar = 0.25 * (((st->w[0] + st->w[1]) + st->w[2]) + st->w[3]);
+        double fa = v.throttle_kv * (st->u_speed - v.throttle_gear * wbar);
         if (fa > v.throttle_force_limit) fa = v.throttle_force_limit;
         if (fa < -v.throttle_force_limit) fa = -v.throttle_force_limit;
         const double ta = (v.throttle_gear * 0.25) * fa;
+        const double wi = st->w[r];
+        const double wx_ = v.wheel_x[r], wy_ = v.wheel_y[r];
+        const double rxw = ch * wx_ - sh * wy_;
+        const double ryw = sh * wx_ + ch * wy_;
+        const double vpx = vx - wz * ryw, vpy = vy + wz * rxw;
+        const double fdx = ch * cwi - sh * swi, fdy = sh * cwi + ch * swi;
+        const double vlong = (vpx * fdx + vpy * fdy) - v.wheel_radius * wi;
+        const double vlat = vpy * fdx - vpx * fdy;
+        double flong = -(v.tire_damping * vlong), flat = -(v.tire_damping * vlat);
+        const double lim = v.friction * L.veh->wheel_load[r];
+        const double m2 = flong * flong + flat * flat;
+        if (m2 > lim * lim) { const double sc = lim / sqrt(m2); flong = flong * sc; flat = flat * sc; }
+        Force t;
+        t.fx = flong * fdx - flat * fdy; t.fy = flong * fdy + flat * fdx; t.tz = rxw * t.fy - ryw * t.fx;
+        const double wn = (v.wheel_inertia * wi + dt * (ta - v.wheel_radius * flong)) / (v.wheel_inertia + dt * v.wheel_damping);
+        if (on) { terms[r] = t; L.wnew[(on ? c : 0) * 4 + r] = wn; }
+    }
+    {   // ---- wall-contact circle r and wheel softener r (a shadowed car collides with nothing, custom.py:1452-1457)
+        const uint32_t* bits = P.bits; const uint32_t* nearbits = P.nearbits;
+        const double x = st->x, y = st->y, vx = st->vx, vy = st->vy, wz = st->wz;
+        Force t = { 0.0, 0.0, 0.0 };
+        if (on && !finished && r < 3)
+            t = wall_circle(P, bits, nearbits, x, y, vx, vy, wz, ch * v.contact_x[r], sh * v.contact_x[r], v.contact_radius, v.contact_stiffness, v.contact_damping);
+        if (on && r < 3) terms[4 + r] = t;
+        Force u = { 0.0, 0.0, 0.0 };
+        if (on && !finished && P.bubble_wrap)          // custom.py:1041-1055, mushr.em.xml:65-67,126-129
+            u = wall_circle(P, bits, nearbits, x, y, vx, vy, wz, ch * v.wheel_x[r] - sh * v.wheel_y[r], sh * v.wheel_x[r] + ch * v.wheel_y[r],
+                            v.softener_radius, v.contact_stiffness, v.contact_damping);
+        if (on) terms[7 + r] = u;
+    }
+    wave_lds_sync();                 // every lane has read the pre-step states; the force terms are staged
+    if (on && r == 0) {
         Force f = { 0.0, 0.0, 0.0 };
-        // rolled on purpose (register pressure): the rear wheels evaluate the polynomials at 0, which gives exactly (1, 0)
         #pragma unroll 1
-        for (int i = 0; i < 4; ++i) {
-            const double ang = (i == 0) ? dfl : ((i == 1) ? dfr : 0.0);
-            const double cwi = spec_cos(ang), swi = spec_sin(ang);
-            const double wi = (i == 0) ? s.w[0] : ((i == 1) ? s.w[1] : ((i == 2) ? s.w[2] : s.w[3]));
-            const double wx_ = v.wheel_x[i], wy_ = v.wheel_y[i];
-            const double rxw = ch * wx_ - sh * wy_;
-            const double ryw = sh * wx_ + ch * wy_;
-            const double vpx = s.vx - s.wz * ryw, vpy = s.vy + s.wz * rxw;
-            const double fdx = ch * cwi - sh * swi, fdy = sh * cwi + ch * swi;
-            const double vlong = (vpx * fdx + vpy * fdy) - v.wheel_radius * wi;
-            const double vlat = vpy * fdx - vpx * fdy;
-            double flong = -(v.tire_damping * vlong), flat = -(v.tire_damping * vlat);
-            const double lim = v.friction * L.veh->wheel_load[i];
-            const double m2 = flong * flong + flat * flat;
-            if (m2 > lim * lim) { const double sc = lim / sqrt(m2); flong = flong * sc; flat = flat * sc; }
-            const double fx = flong * fdx - flat * fdy, fy = flong * fdy + flat * fdx;
-            f.fx += fx; f.fy += fy; f.tz += rxw * fy - ryw * fx;
-            const double wn = (v.wheel_inertia * wi + dt * (ta - v.wheel_radius * flong)) / (v.wheel_inertia + dt * v.wheel_damping);
-            if (i == 0) o.w[0] = wn; else if (i == 1) o.w[1] = wn; else if (i == 2) o.w[2] = wn; else o.w[3] = wn;
-        }
-        if (!finished) {          // a shadowed car collides with nothing (custom.py:1452-1457)
-            const uint32_t* bits = P.bits; const uint32_t* nearbits = P.nearbits;
-            #pragma unroll 1
-            for (int k = 0; k < 3; ++k) {           // chassis circles
-                const double rxw = ch * v.contact_x[k], ryw = sh * v.contact_x[k];
-                wall_circle(P, bits, nearbits, s.x, s.y, s.vx, s.vy, s.wz, rxw, ryw, v.contact_radius, v.contact_stiffness, v.contact_damping, f);
-            }
-            if (P.bubble_wrap) {                    // wheel softeners against the walls (custom.py:1041-1055, mushr.em.xml:65-67,126-129)
-                #pragma unroll 1
-                for (int k = 0; k < 4; ++k) {
-                    const double rxw = ch * v.wheel_x[k] - sh * v.wheel_y[k], ryw = sh * v.wheel_x[k] + ch * v.wheel_y[k];
-                    wall_circle(P, bits, nearbits, s.x, s.y, s.vx, s.vy, s.wz, rxw, ryw, v.softener_radius, v.contact_stiffness, v.contact_damping, f);
-                }
-            }
-            if (MULTI) car_contact(P, v, s, ch, sh, L.cars + (lane - lane % P.cars_per_env), lane % P.cars_per_env, f);
-        }
-        o.vx = s.vx + dt * (f.fx / v.mass);
-        o.vy = s.vy + dt * (f.fy / v.mass);
-        o.wz = s.wz + dt * (f.tz / v.izz);
+        for (int k = 0; k < FTGP_FORCE_TERMS; ++k) { const Force t = terms[k]; f.fx += t.fx; f.fy += t.fy; f.tz += t.tz; }
+        if (MULTI && !finished) car_contact(P, v, st, ch, sh, L.cars + (c - c % P.cars_per_env), c % P.cars_per_env, f);
+        Dyn o;
+        o.vx = st->vx + dt * (f.fx / v.mass);
+        o.vy = st->vy + dt * (f.fy / v.mass);
+        o.wz = st->wz + dt * (f.tz / v.izz);
         // position servo on the steering joint, implicit damping (mushr.em.xml:78,179)
-        o.qsd = (v.steer_inertia * s.qsd + dt * (v.steer_kp * (u_steer - s.qs))) / (v.steer_inertia + dt * v.steer_damping);
-        o.qs = s.qs + dt * o.qsd;
+        o.qsd = (v.steer_inertia * st->qsd + dt * (v.steer_kp * (st->u_steer - st->qs))) / (v.steer_inertia + dt * v.steer_damping);
+        o.qs = st->qs + dt * o.qsd;
         if (o.qs > v.steer_limit) { o.qs = v.steer_limit; if (o.qsd > 0.0) o.qsd = 0.0; }
         if (o.qs < -v.steer_limit) { o.qs = -v.steer_limit; if (o.qsd < 0.0) o.qsd = 0.0; }
         // semi-implicit Euler: positions with the new velocities
         const double h = (0.5 * dt) * o.wz;
         const double chh = spec_cos(h), shh = spec_sin(h);
-        const double nw = s.qw * chh - s.qz * shh, nz = s.qz * chh + s.qw * shh;
+        const double nw = qw * chh - qz * shh, nz = qz * chh + qw * shh;
         const double n = sqrt(nw * nw + nz * nz);
-        o.x = s.x + dt * o.vx;
-        o.y = s.y + dt * o.vy;
+        o.x = st->x + dt * o.vx;
+        o.y = st->y + dt * o.vy;
         o.qw = nw / n; o.qz = nz / n;
+        o.w[0] = L.wnew[c * 4]; o.w[1] = L.wnew[c * 4 + 1]; o.w[2] = L.wnew[c * 4 + 2]; o.w[3] = L.wnew[c * 4 + 3];
+        L.next[c] = o;               // committed below, after every car of the workgroup has read its neighbours' pre-step states
     }
-    wave_lds_sync();                 // every lane has read the pre-step states
-    if (on) {
-        *reinterpret_cast<Dyn*>(st) = o;
-        L.steps[lane] += 1;
+    wave_lds_sync();
+    {   // commit: the 13 doubles of the new dynamic state, spread over the car's four lanes
+        if (on) {
+            const double* src = reinterpret_cast<const double*>(L.next + c);
+            double* dst = reinterpret_cast<double*>(st);
+            for (int k = r; k < (int)(sizeof(Dyn) / sizeof(double)); k += 4) dst[k] = src[k];
+            if (r == 0) L.steps[c] += 1;
+        }
     }
     wave_lds_sync();
     // ---- K3: distances = ((path - xpos)**2).sum(1); closest = distances.argmin() (first minimum), then the race-state update
-    const int c = lane >> 2, part = lane & 3;
-    const bool onp = c < ncars_here;
-    CarCore* sc = L.cars + (onp ? c : 0);
-    const double x = sc->x, y = sc->y;
-    int idx = part * (FTGP_PATH_POINTS / 4);
+    const double x = st->x, y = st->y;
+    int idx = r * (FTGP_PATH_POINTS / 4);
     double best;
     {
         const double dx = L.path[2 * idx] - x, dy = L.path[2 * idx + 1] - y;
         best = dx * dx + dy * dy;
     }
     #pragma unroll 1
-    for (int i = idx + 1; i < (part + 1) * (FTGP_PATH_POINTS / 4); ++i) {
+    for (int i = idx + 1; i < (r + 1) * (FTGP_PATH_POINTS / 4); ++i) {
         const double dx = L.path[2 * i] - x, dy = L.path[2 * i + 1] - y;
         const double d = dx * dx + dy * dy;
         if (d < best) { best = d; idx = i; }
@@ -550,14 +571,14 @@ __device__ __forceinline__ void dynamics_lanes(const DeviceParams& P, const Lds&
         const int oi = __shfl_xor(idx, m, FTGP_WAVE);
         if (ob < best || (ob == best && oi < idx)) { best = ob; idx = oi; }
     }
-    if (onp && part == 0) {
-        Race r; race_load(r, sc);
-        progress_update(P, r, L.steps[c], idx, best, P.cars[ci0 + c].times);
-        race_store(r, sc);
+    if (on && r == 0) {
+        Race rc; race_load(rc, st);
+        progress_update(P, rc, L.steps[c], idx, best, P.cars[ci0 + c].times);
+        race_store(rc, st);
     }
     wave_lds_sync();
     // the LiDAR frames of the next step (its sweep starts after the workgroup barrier that ends this step)
-    if (on) frame_write(P, L.veh->v, st, next_frames + lane);
+    if (on && r == 0) frame_write(P, v, st, next_frames + c);
 }
 
 // =============================================================================================

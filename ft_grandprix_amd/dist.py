@@ -1,10 +1,18 @@
 """Multi-GPU layout of the hot path: envs are independent worlds, so a batch is cut into
 contiguous shards, one handle (one process, one GPU) per shard, with no data-path collective.  The only exchange
 is the end-of-step metrics all-gather: RCCL over xGMI from the C shim (``Env.metrics_allgather``) on GPUs, or any
-object exposing ``all_gather(np.ndarray) -> list[np.ndarray]`` (the CPU tests use torch.distributed / gloo)."""
+object exposing ``all_gather(np.ndarray) -> np.ndarray`` (``Rendezvous`` below; the CPU tests also use gloo).
+
+``Rendezvous`` is the host-side plumbing one process per GPU needs around that -- shipping the 128-byte RCCL id from
+rank 0, a barrier, the max-over-ranks of a timing -- over plain TCP on the launcher's MASTER_ADDR, so the host path
+needs neither PyTorch nor MPI."""
 from __future__ import annotations
 
-from typing import Dict, Optional, Tuple
+import os
+import socket
+import struct
+import time
+from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 
@@ -56,3 +64,144 @@ def gather_metrics(env: capi.Env, comm: Optional[object] = None) -> np.ndarray:
     if comm is None:
         return env.metrics_allgather()
     return comm.all_gather(env.metrics_local())
+
+
+class Rendezvous:
+    """All ranks of one job on one node: rank 0 listens, the others connect; every operation is a gather at rank 0
+    followed by a broadcast (a few hundred bytes -- latency is irrelevant, ordering is what matters).
+
+    The launcher's MASTER_PORT itself belongs to the launcher's own store, so the exchange uses MASTER_PORT + 1 + k for
+    the first k in 0..15 that rank 0 can bind; clients find it by a handshake carrying the job token."""
+
+    MAGIC = b"FTGPRDZV"
+
+    def __init__(self, rank: int, world: int, addr: str = "127.0.0.1", port: int = 29500, token: str = "", timeout: float = 120.0):
+        if not (0 <= rank < world):
+            raise ValueError("rank out of range")
+        self.rank, self.world, self.timeout = rank, world, timeout
+        self.peers: List[Optional[socket.socket]] = [None] * world
+        self.sock: Optional[socket.socket] = None
+        hello = self.MAGIC + token.encode()[:56].ljust(56, b"\0")
+        if world == 1:
+            return
+        if rank == 0:
+            srv, err = None, None
+            for k in range(16):
+                try:
+                    srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                    srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                    srv.bind((addr, port + 1 + k)); srv.listen(world)
+                    break
+                except OSError as e:
+                    err, srv = e, None
+            if srv is None:
+                raise OSError(f"rendezvous: no free port near {port}: {err}")
+            srv.settimeout(timeout)
+            got = 0
+            while got < world - 1:
+                c, _ = srv.accept()
+                c.settimeout(timeout); c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                h = self._recv_exact(c, len(hello) + 4)
+                r = struct.unpack("<i", h[len(hello):])[0]
+                if h[:len(hello)] != hello or not (0 < r < world) or self.peers[r] is not None:
+                    c.close(); continue                 # somebody else's client
+                c.sendall(b"OK"); self.peers[r] = c; got += 1
+            srv.close()
+        else:
+            deadline = time.time() + timeout
+            while self.sock is None:
+                for k in range(16):
+                    try:
+                        c = socket.create_connection((addr, port + 1 + k), timeout=2.0)
+                        c.settimeout(timeout); c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                        c.sendall(hello + struct.pack("<i", rank))
+                        if self._recv_exact(c, 2) == b"OK":
+                            self.sock = c
+                            break
+                        c.close()
+                    except OSError:
+                        continue
+                if self.sock is None:
+                    if time.time() > deadline:
+                        raise TimeoutError("rendezvous: rank 0 did not answer")
+                    time.sleep(0.05)
+
+    @classmethod
+    def from_env(cls, timeout: float = 120.0) -> "Rendezvous":
+        """RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT as torch.distributed.run (or bench.py's own launcher) export them."""
+        return cls(int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
+                   os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29500")),
+                   os.environ.get("TORCHELASTIC_RUN_ID", os.environ.get("FTGP_JOB_TOKEN", "")), timeout)
+
+    @staticmethod
+    def _recv_exact(c: socket.socket, n: int) -> bytes:
+        buf = b""
+        while len(buf) < n:
+            part = c.recv(n - len(buf))
+            if not part:
+                raise ConnectionError("rendezvous: peer closed the connection")
+            buf += part
+        return buf
+
+    def _send(self, c: socket.socket, data: bytes):
+        c.sendall(struct.pack("<I", len(data)) + data)
+
+    def _recv(self, c: socket.socket) -> bytes:
+        return self._recv_exact(c, struct.unpack("<I", self._recv_exact(c, 4))[0])
+
+    def allgather_bytes(self, data: bytes) -> List[bytes]:
+        """Every rank's payload, in rank order, on every rank."""
+        if self.world == 1:
+            return [data]
+        if self.rank == 0:
+            parts = [data] + [self._recv(self.peers[r]) for r in range(1, self.world)]
+            blob = b"".join(struct.pack("<I", len(p)) + p for p in parts)
+            for r in range(1, self.world):
+                self._send(self.peers[r], blob)
+            return parts
+        self._send(self.sock, data)
+        blob, parts, o = self._recv(self.sock), [], 0
+        for _ in range(self.world):
+            n = struct.unpack("<I", blob[o:o + 4])[0]
+            parts.append(blob[o + 4:o + 4 + n]); o += 4 + n
+        return parts
+
+    def broadcast_bytes(self, data: Optional[bytes]) -> bytes:
+        """Rank 0's payload on every rank (the other ranks pass None)."""
+        return self.allgather_bytes(data if self.rank == 0 else b"")[0]
+
+    def barrier(self):
+        self.allgather_bytes(b"")
+
+    def all_gather(self, rec: np.ndarray) -> np.ndarray:
+        """[world, ...] stack of every rank's float64 record (same interface as GlooGather)."""
+        r = np.ascontiguousarray(rec, dtype=np.float64)
+        return np.stack([np.frombuffer(p, dtype=np.float64).reshape(r.shape) for p in self.allgather_bytes(r.tobytes())])
+
+    def max(self, values) -> np.ndarray:
+        """Element-wise maximum over ranks."""
+        return self.all_gather(np.asarray(values, dtype=np.float64)).max(axis=0)
+
+    def close(self):
+        for c in self.peers + [self.sock]:
+            if c is not None:
+                try:
+                    c.close()
+                except OSError:
+                    pass
+        self.peers, self.sock = [None] * self.world, None
+
+
+def exchange_unique_id(rdzv: Rendezvous, make_id) -> bytes:
+    """Rank 0 creates the RCCL unique id with ``make_id()`` and ships it; a failure on rank 0 travels as a marker, so
+    that every rank raises together instead of leaving the others blocked in the exchange."""
+    payload = None
+    if rdzv.rank == 0:
+        try:
+            payload = b"\x01" + bytes(make_id())
+        except Exception as exc:            # noqa: BLE001 - forwarded to every rank
+            payload = b"\x00" + str(exc).encode()[:400]
+    got = rdzv.broadcast_bytes(payload)
+    if got[:1] != b"\x01":
+        raise RuntimeError("rank 0 could not create the RCCL id: " + got[1:].decode(errors="replace"))
+    return got[1:]

@@ -90,3 +90,57 @@ def test_world_size_2_gloo_metrics_allgather(oracle):
     assert tot["ranks"] == 2
     for k in capi.METRIC_FIELDS:
         assert tot[k] == ref[k], k
+
+
+def _rdzv_main(rank, world, port, q):
+    """One rank of a torch-free job: shard + metrics gather over ft_grandprix_amd.dist.Rendezvous, and the id exchange
+    with a failing rank 0 (every rank must raise together, none may stay blocked)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), FTGP_JOB_TOKEN="t-rdzv")
+    sys.path.insert(0, ROOT)
+    from tests.helpers import load_oracle
+    rdzv = ftdist.Rendezvous.from_env(timeout=60)
+    try:
+        uid = ftdist.exchange_unique_id(rdzv, lambda: bytes(range(128)))
+        try:
+            ftdist.exchange_unique_id(rdzv, lambda: (_ for _ in ()).throw(RuntimeError("librccl.so not loadable")))
+            err = ""
+        except RuntimeError as exc:
+            err = str(exc)
+        ora = load_oracle()
+        t = load_track("circle")
+        with ftdist.make_shard(ora, t, 12, rank, world, n_rays=36, spawn_mode=1, seed=5, lap_target=1) as sh:
+            sh.rollout("fast", 150)
+            recs = ftdist.gather_metrics(sh, rdzv)
+            rdzv.barrier()
+            tmax = rdzv.max([float(rank), 10.0 - rank])
+            q.put((rank, recs, sh.metrics_local(), uid, err, tmax))
+    finally:
+        rdzv.close()
+
+
+def test_world_size_3_tcp_rendezvous_without_torch(oracle):
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world = 3
+    procs = [ctx.Process(target=_rdzv_main, args=(r, world, port, q)) for r in range(world)]
+    for p in procs: p.start()
+    out = sorted((q.get(timeout=120) for _ in procs), key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(world):
+        np.testing.assert_array_equal(out[0][1], out[r][1])          # every rank holds every rank's record, in rank order
+        np.testing.assert_array_equal(out[0][1][r], out[r][2])
+        assert out[r][3] == bytes(range(128))                       # the 128-byte id arrived on every rank
+        assert "librccl.so not loadable" in out[r][4]                # ... and so did rank 0's failure
+        np.testing.assert_array_equal(out[r][5], [world - 1.0, 10.0])
+    t = load_track("circle")
+    with capi.Env(oracle, t, n_envs=12, n_rays=36, spawn_mode=1, seed=5, lap_target=1) as mono:
+        mono.rollout("fast", 150)
+        ref = ftdist.reduce_metrics(mono.metrics_local()[None])
+    tot = ftdist.reduce_metrics(out[0][1])
+    assert tot["ranks"] == world
+    for k in capi.METRIC_FIELDS:
+        assert tot[k] == ref[k], k
