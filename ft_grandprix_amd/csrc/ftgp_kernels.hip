@@ -336,23 +336,22 @@ __device__ __forceinline__ uint32_t wall_window(const uint32_t* __restrict__ row
     return sh ? ((lo >> sh) | (hi << (32 - sh))) : lo;
 }
 
-// One circle (centre = car position + (rxw, ryw), radius r) against the wall pixels: the deepest penetration wins,
-// ties go to the first pixel in raster order; penalty spring/damper along the contact normal.  Returns the force term
-// (zero when nothing is touched).
-__device__ __forceinline__ Force wall_circle(const DeviceParams& P, const uint32_t* __restrict__ bits, const uint32_t* __restrict__ nearbits,
-                                             double sx_, double sy_, double vx, double vy, double wz, double rxw, double ryw, double r,
-                                             double stiffness, double damping)
+// One circle (centre (px, py), radius r) against the wall pixels, in two parts so that neither keeps the other's values in
+// registers (the kernel runs under a 64-VGPR budget): the search returns the pixel of deepest penetration -- ties go to the
+// first pixel in raster order -- and the force part turns it into the penalty spring/damper term along the contact normal.
+struct WallHit { double pen; int cx, cy; bool found; };
+
+__device__ __forceinline__ WallHit wall_search(const DeviceParams& P, const uint32_t* __restrict__ bits, const uint32_t* __restrict__ nearbits,
+                                               double px, double py, double r)
 {
-    Force out = { 0.0, 0.0, 0.0 };
+    WallHit h; h.pen = 0.0; h.cx = 0; h.cy = 0; h.found = false;
     const int W = P.width, H = P.height, wpr = P.words_per_row;
     const double sx = P.px_size_x, sy = P.px_size_y;
     const int nx = (int)ceil(r * P.inv_px_x), ny = (int)ceil(r * P.inv_px_y);
-    const double px = sx_ + rxw, py = sy_ + ryw;
     const double u = (px - P.origin_x) * P.inv_px_x, w = (P.origin_y - py) * P.inv_px_y;
     const int ix = (int)floor(u), iy = (int)floor(w);
-    if (ix < 0 || ix >= W || iy < 0 || iy >= H) return out;
-    if (!((nearbits[(size_t)iy * wpr + (ix >> 5)] >> (ix & 31)) & 1u)) return out;      // no wall pixel within the window
-    double best = 0.0; int bcx = 0, bcy = 0; bool found = false;
+    if (ix < 0 || ix >= W || iy < 0 || iy >= H) return h;
+    if (!((nearbits[(size_t)iy * wpr + (ix >> 5)] >> (ix & 31)) & 1u)) return h;      // no wall pixel within the window
     const int wx = 2 * nx + 1;
     for (int dy = -ny; dy <= ny; ++dy) {
         const int cy = iy + dy;
@@ -373,13 +372,20 @@ __device__ __forceinline__ Force wall_circle(const DeviceParams& P, const uint32
                 const double d2 = ex * ex + ey * ey;
                 if (d2 >= r * r) continue;
                 const double pen = r - sqrt(d2);
-                if (!found || pen > best) { best = pen; bcx = cx; bcy = cy; found = true; }
+                if (!h.found || pen > h.pen) { h.pen = pen; h.cx = cx; h.cy = cy; h.found = true; }
             }
         }
     }
-    if (!found) return out;
-    const double x0w = P.origin_x + (double)bcx * sx, x1w = x0w + sx;
-    const double y1w = P.origin_y - (double)bcy * sy, y0w = y1w - sy;
+    return h;
+}
+
+__device__ __forceinline__ Force wall_force(const DeviceParams& P, const WallHit& h, double px, double py, double vx, double vy, double wz,
+                                            double rxw, double ryw, double stiffness, double damping)
+{
+    Force out = { 0.0, 0.0, 0.0 };
+    const double sx = P.px_size_x, sy = P.px_size_y;
+    const double x0w = P.origin_x + (double)h.cx * sx, x1w = x0w + sx;
+    const double y1w = P.origin_y - (double)h.cy * sy, y0w = y1w - sy;
     const double qx = px < x0w ? x0w : (px > x1w ? x1w : px);
     const double qy = py < y0w ? y0w : (py > y1w ? y1w : py);
     const double ex = px - qx, ey = py - qy;
@@ -393,10 +399,37 @@ __device__ __forceinline__ Force wall_circle(const DeviceParams& P, const uint32
     }
     const double vcx = vx - wz * ryw, vcy = vy + wz * rxw;
     const double vn = vcx * nxv + vcy * nyv;
-    const double mag = stiffness * best - damping * vn;
+    const double mag = stiffness * h.pen - damping * vn;
     if (mag <= 0.0) return out;
     out.fx = mag * nxv; out.fy = mag * nyv; out.tz = rxw * out.fy - ryw * out.fx;
     return out;
+}
+
+// everything a later block needs is re-read from LDS after this point instead of being carried in registers
+#define FTGP_FORGET_REGISTERS() asm volatile("" ::: "memory")
+
+// chassis circle k (body (contact_x[k], 0)) or wheel softener k (body (wheel_x[k], wheel_y[k])) of car `st` against the walls
+__device__ __forceinline__ Force wall_term(const DeviceParams& P, const FtgpVehicle& v, const CarCore* st, int k, bool softener)
+{
+    WallHit h; double px, py;
+    {
+        const double qw = st->qw, qz = st->qz;
+        const double ch = 1.0 - 2.0 * (qz * qz), sh = 2.0 * (qw * qz);
+        const double rxw = softener ? ch * v.wheel_x[k] - sh * v.wheel_y[k] : ch * v.contact_x[k];
+        const double ryw = softener ? sh * v.wheel_x[k] + ch * v.wheel_y[k] : sh * v.contact_x[k];
+        px = st->x + rxw; py = st->y + ryw;
+        h = wall_search(P, P.bits, P.nearbits, px, py, softener ? v.softener_radius : v.contact_radius);
+    }
+    FTGP_FORGET_REGISTERS();
+    Force t = { 0.0, 0.0, 0.0 };
+    if (h.found) {
+        const double qw = st->qw, qz = st->qz;
+        const double ch = 1.0 - 2.0 * (qz * qz), sh = 2.0 * (qw * qz);
+        const double rxw = softener ? ch * v.wheel_x[k] - sh * v.wheel_y[k] : ch * v.contact_x[k];
+        const double ryw = softener ? sh * v.wheel_x[k] + ch * v.wheel_y[k] : sh * v.contact_x[k];
+        t = wall_force(P, h, px, py, st->vx, st->vy, st->wz, rxw, ryw, v.contact_stiffness, v.contact_damping);
+    }
+    return t;
 }
 
 // Circles of this car against the circles of the other cars of the env (penalty spring/damper, pre-step states).
@@ -469,9 +502,9 @@ __device__ __forceinline__ void dynamics_lanes(const DeviceParams& P, const Lds&
     const FtgpVehicle& v = L.veh->v;
     const double dt = P.dt;
     const bool finished = st->finished != 0;
-    const double qw = st->qw, qz = st->qz;
-    const double ch = 1.0 - 2.0 * (qz * qz), sh = 2.0 * (qw * qz);
     {   // ---- wheel r
+        const double qw = st->qw, qz = st->qz;
+        const double ch = 1.0 - 2.0 * (qz * qz), sh = 2.0 * (qw * qz);
         const double vx = st->vx, vy = st->vy, wz = st->wz;
         // Ackermann coupling, mushr.em.xml:185-186: q + 0.375 q^2 + 0.140625 q^3 - 0.0722656 q^4 (fl), the odd signs flipped for fr
         const double q = st->qs;
@@ -502,25 +535,27 @@ __device__ __forceinline__ void dynamics_lanes(const DeviceParams& P, const Lds&
         const double wn = (v.wheel_inertia * wi + dt * (ta - v.wheel_radius * flong)) / (v.wheel_inertia + dt * v.wheel_damping);
         if (on) { terms[r] = t; L.wnew[(on ? c : 0) * 4 + r] = wn; }
     }
+    FTGP_FORGET_REGISTERS();
     {   // ---- wall-contact circle r and wheel softener r (a shadowed car collides with nothing, custom.py:1452-1457)
-        const uint32_t* bits = P.bits; const uint32_t* nearbits = P.nearbits;
-        const double x = st->x, y = st->y, vx = st->vx, vy = st->vy, wz = st->wz;
         Force t = { 0.0, 0.0, 0.0 };
-        if (on && !finished && r < 3)
-            t = wall_circle(P, bits, nearbits, x, y, vx, vy, wz, ch * v.contact_x[r], sh * v.contact_x[r], v.contact_radius, v.contact_stiffness, v.contact_damping);
+        if (on && !finished && r < 3) t = wall_term(P, v, st, r, false);
         if (on && r < 3) terms[4 + r] = t;
+        FTGP_FORGET_REGISTERS();
         Force u = { 0.0, 0.0, 0.0 };
-        if (on && !finished && P.bubble_wrap)          // custom.py:1041-1055, mushr.em.xml:65-67,126-129
-            u = wall_circle(P, bits, nearbits, x, y, vx, vy, wz, ch * v.wheel_x[r] - sh * v.wheel_y[r], sh * v.wheel_x[r] + ch * v.wheel_y[r],
-                            v.softener_radius, v.contact_stiffness, v.contact_damping);
+        if (on && !finished && P.bubble_wrap) u = wall_term(P, v, st, r, true);        // custom.py:1041-1055, mushr.em.xml:65-67,126-129
         if (on) terms[7 + r] = u;
     }
+    FTGP_FORGET_REGISTERS();
     wave_lds_sync();                 // every lane has read the pre-step states; the force terms are staged
     if (on && r == 0) {
         Force f = { 0.0, 0.0, 0.0 };
         #pragma unroll 1
         for (int k = 0; k < FTGP_FORCE_TERMS; ++k) { const Force t = terms[k]; f.fx += t.fx; f.fy += t.fy; f.tz += t.tz; }
-        if (MULTI && !finished) car_contact(P, v, st, ch, sh, L.cars + (c - c % P.cars_per_env), c % P.cars_per_env, f);
+        const double qw = st->qw, qz = st->qz;
+        if (MULTI && !finished) {
+            const double ch = 1.0 - 2.0 * (qz * qz), sh = 2.0 * (qw * qz);
+            car_contact(P, v, st, ch, sh, L.cars + (c - c % P.cars_per_env), c % P.cars_per_env, f);
+        }
         Dyn o;
         o.vx = st->vx + dt * (f.fx / v.mass);
         o.vy = st->vy + dt * (f.fy / v.mass);
@@ -585,7 +620,9 @@ __device__ __forceinline__ void dynamics_lanes(const DeviceParams& P, const Lds&
 // K5: on-device drivers.  nidc.py:12-131 / fast.py:11-139 restated for one wave; the previous scan sits in LDS.
 // =============================================================================================
 // number of points one disparity covers: ceil(2 * atan(width / (2 * close_dist)) / radians_per_point), nidc.py:57,93-99
-__device__ __forceinline__ int cover_count(double width, double rpp, double close_dist)
+// (kept out of line: the binary64 atan carries some twenty polynomial constants that would otherwise be hoisted into registers
+// around the driver's loops; internal linkage lets the callers' register budget apply to it)
+static __device__ __attribute__((noinline)) int cover_count(double width, double rpp, double close_dist)
 {
     const double angle = 2 * atan(width / (2 * close_dist));
     const double cnt = ceil(angle / rpp);
@@ -698,8 +735,8 @@ __device__ __forceinline__ void policy_apply(const DeviceParams& P, int policy, 
     }
     switch (policy) {
     case FTGP_POLICY_LOBOTOMY: if (lane0) { st->u_speed = 0.0; st->u_steer = 0.0; } break;   // lobotomy.py:2-3
-    case FTGP_POLICY_NIDC: policy_disparity(P, scan, st, false, list); break;
-    case FTGP_POLICY_FAST: policy_disparity(P, scan, st, true, list); break;
+    case FTGP_POLICY_NIDC:
+    case FTGP_POLICY_FAST: policy_disparity(P, scan, st, policy == FTGP_POLICY_FAST, list); break;
     case FTGP_POLICY_RANDOM: {
         uint64_t h = splitmix64(P.seed + (uint64_t)((long)P.env_base * P.cars_per_env + ci) * 0x9E3779B97F4A7C15ull);
         h = splitmix64(h ^ (uint64_t)steps);
