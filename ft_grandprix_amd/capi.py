@@ -17,7 +17,7 @@ from .track import Track
 
 ABI_VERSION = 2
 PATH_POINTS = 100
-MAX_LAP_TIMES = 16
+MAX_LAP_TIMES = 32
 SNAPSHOT_DOUBLES = 10
 POSE_DOUBLES = 13
 PROGRESS_INTS = 9

@@ -78,6 +78,7 @@ struct FtgpEnv {
     double* d_metrics = nullptr; double* d_gather = nullptr;
     int32_t* d_prog = nullptr; double* d_core = nullptr;
     std::vector<int32_t> h_prog; std::vector<double> h_core;
+    bool rows_valid = false;          // h_prog / h_core mirror the device state (cleared by every call that changes it)
     bool multi = false;
     // comm
     void* comm = nullptr; int rank = 0, world = 1;
@@ -173,6 +174,7 @@ int lds_layout(DeviceParams& P, int cpb, int wpb)
 
 int launch_steps(FtgpEnv* e, int policy, int n_steps)
 {
+    e->rows_valid = false;
     if (n_steps < 0) return fail(FTGP_ERR_ARG, "n_steps < 0%s");
     if (policy == FTGP_POLICY_NIDC || policy == FTGP_POLICY_FAST) {
         if (e->P.n_rays < 8) return fail(FTGP_ERR_ARG, "nidc/fast need n_rays >= 8 (they drop len/8 rays from each end)%s");
@@ -197,6 +199,7 @@ int launch_steps(FtgpEnv* e, int policy, int n_steps)
 // packed read-back rows (one small kernel + two small copies instead of the whole state records)
 int sync_rows_to_host(FtgpEnv* e)
 {
+    if (e->rows_valid) return 0;      // a host-driver step reads snapshot, progress and lap times: one pack, not three
     HIP_TRY(hipSetDevice(e->device));
     const size_t n = (size_t)e->P.n_cars;
     e->h_prog.resize(n * FTGP_PROGRESS_INTS); e->h_core.resize(n * kCoreDoubles);
@@ -205,6 +208,7 @@ int sync_rows_to_host(FtgpEnv* e)
     HIP_TRY(hipMemcpyAsync(e->h_prog.data(), e->d_prog, sizeof(int32_t) * e->h_prog.size(), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipMemcpyAsync(e->h_core.data(), e->d_core, sizeof(double) * e->h_core.size(), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
+    e->rows_valid = true;
     return 0;
 }
 
@@ -467,6 +471,7 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
 int ftgp_reset(FtgpEnv* e, const uint8_t* mask)
 {
     if (!e) return fail(FTGP_ERR_ARG, "null handle%s");
+    e->rows_valid = false;
     HIP_TRY(hipSetDevice(e->device));
     const uint8_t* dmask = nullptr;
     if (mask) {
@@ -484,6 +489,7 @@ int ftgp_reset(FtgpEnv* e, const uint8_t* mask)
 int ftgp_set_ctrl(FtgpEnv* e, const double* ctrl, const uint8_t* car_mask)
 {
     if (!e || !ctrl) return fail(FTGP_ERR_ARG, "null argument%s");
+    e->rows_valid = false;
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipMemcpyAsync(e->d_ctrl, ctrl, sizeof(double) * 2 * (size_t)e->P.n_cars, hipMemcpyHostToDevice, e->stream));
     const uint8_t* dmask = nullptr;
@@ -557,6 +563,7 @@ int ftgp_get_pose(FtgpEnv* e, double* out)
 int ftgp_set_pose(FtgpEnv* e, const double* pose)
 {
     if (!e || !pose) return fail(FTGP_ERR_ARG, "null argument%s");
+    e->rows_valid = false;
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipMemcpyAsync(e->d_pose, pose, sizeof(double) * FTGP_POSE_DOUBLES * (size_t)e->P.n_cars, hipMemcpyHostToDevice, e->stream));
     hipLaunchKernelGGL(ftgp_set_pose_kernel, dim3((e->P.n_cars + 255) / 256), dim3(256), 0, e->stream, e->P, e->d_pose);
@@ -568,6 +575,7 @@ int ftgp_set_pose(FtgpEnv* e, const double* pose)
 int ftgp_policy_eval(FtgpEnv* e, int policy, const float* ranges, double* ctrl_out)
 {
     if (!e || !ranges) return fail(FTGP_ERR_ARG, "null argument%s");
+    e->rows_valid = false;
     if (policy < FTGP_POLICY_LOBOTOMY || policy > FTGP_POLICY_RANDOM) return fail(FTGP_ERR_ARG, "policy_eval: device policies only%s");
     if (policy == FTGP_POLICY_NIDC || policy == FTGP_POLICY_FAST) {
         if (e->P.n_rays < 8) return fail(FTGP_ERR_ARG, "nidc/fast need n_rays >= 8%s");
@@ -588,6 +596,7 @@ int ftgp_policy_eval(FtgpEnv* e, int policy, const float* ranges, double* ctrl_o
 int ftgp_eval_progress(FtgpEnv* e)
 {
     if (!e) return fail(FTGP_ERR_ARG, "null handle%s");
+    e->rows_valid = false;
     HIP_TRY(hipSetDevice(e->device));
     hipLaunchKernelGGL(ftgp_progress_kernel, dim3((e->P.n_cars + 63) / 64), dim3(64), 0, e->stream, e->P);
     HIP_TRY(hipGetLastError());

@@ -33,22 +33,6 @@ class LobotomyDriver:
         return 0, 0
 
 
-def ordinal(n) -> str:
-    """1 -> '1st' ... as custom.py:47-55 (including its 11th/12th/13th and '0th' rules)."""
-    n = str(n)
-    if n == "0" or (len(n) > 1 and n[-2] == "1"):
-        e = "th"
-    elif n[-1] == "1":
-        e = "st"
-    elif n[-1] == "2":
-        e = "nd"
-    elif n[-1] == "3":
-        e = "rd"
-    else:
-        e = "th"
-    return n + e
-
-
 def lap_completion(completion: int, good_start: bool) -> int:
     """custom.py:132-140: negative while running a lap that was entered backwards."""
     return completion if good_start else -(100 - completion)

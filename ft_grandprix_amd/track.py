@@ -133,6 +133,78 @@ class _Quad:
         return _segment_length(self, 0.0, 1.0, self.point(0), self.point(1), 0)
 
 
+class _Arc:
+    """Elliptical arc, SVG endpoint parameterisation (svg.path 6.3 ``Arc``): centre / start angle / sweep from the two
+    endpoints, radii, x-axis rotation and the large-arc / sweep flags; radii too small for the chord are scaled up."""
+
+    def __init__(self, start, radius, rotation, arc, sweep, end):
+        self.start, self.radius, self.rotation, self.arc, self.sweep, self.end = start, radius, rotation, bool(arc), bool(sweep), end
+        self._parameterize()
+
+    def _parameterize(self):
+        if self.start == self.end:
+            return                                  # degenerate: a point
+        if self.radius.real == 0 or self.radius.imag == 0:
+            return                                  # degenerate: a straight line
+        cosr, sinr = math.cos(math.radians(self.rotation)), math.sin(math.radians(self.rotation))
+        dx, dy = (self.start.real - self.end.real) / 2, (self.start.imag - self.end.imag) / 2
+        x1prim, y1prim = cosr * dx + sinr * dy, -sinr * dx + cosr * dy
+        x1prim_sq, y1prim_sq = x1prim * x1prim, y1prim * y1prim
+        rx, ry = self.radius.real, self.radius.imag
+        rx_sq, ry_sq = rx * rx, ry * ry
+        radius_scale = (x1prim_sq / rx_sq) + (y1prim_sq / ry_sq)
+        if radius_scale > 1:
+            radius_scale = math.sqrt(radius_scale)
+            rx *= radius_scale; ry *= radius_scale
+            rx_sq, ry_sq = rx * rx, ry * ry
+            self.radius_scale = radius_scale
+        else:
+            self.radius_scale = 1
+        t1, t2 = rx_sq * y1prim_sq, ry_sq * x1prim_sq
+        c = math.sqrt(abs((rx_sq * ry_sq - t1 - t2) / (t1 + t2)))
+        if self.arc == self.sweep:
+            c = -c
+        cxprim, cyprim = c * rx * y1prim / ry, -c * ry * x1prim / rx
+        self.center = complex((cosr * cxprim - sinr * cyprim) + ((self.start.real + self.end.real) / 2),
+                              (sinr * cxprim + cosr * cyprim) + ((self.start.imag + self.end.imag) / 2))
+        ux, uy = (x1prim - cxprim) / rx, (y1prim - cyprim) / ry
+        vx, vy = (-x1prim - cxprim) / rx, (-y1prim - cyprim) / ry
+        n = math.sqrt(ux * ux + uy * uy)
+        theta = math.degrees(math.acos(max(-1.0, min(1.0, ux / n))))
+        if uy < 0:
+            theta = -theta
+        self.theta = theta % 360
+        n = math.sqrt((ux * ux + uy * uy) * (vx * vx + vy * vy))
+        d = max(-1.0, min(1.0, (ux * vx + uy * vy) / n))
+        delta = math.degrees(math.acos(d))
+        if (ux * vy - uy * vx) < 0:
+            delta = -delta
+        self.delta = delta % 360
+        if not self.sweep:
+            self.delta -= 360
+
+    def point(self, pos):
+        if self.start == self.end:
+            return self.start
+        if self.radius.real == 0 or self.radius.imag == 0:
+            return self.start + (self.end - self.start) * pos
+        angle = math.radians(self.theta + (self.delta * pos))
+        cosr, sinr = math.cos(math.radians(self.rotation)), math.sin(math.radians(self.rotation))
+        radius = self.radius * self.radius_scale
+        x = cosr * math.cos(angle) * radius.real - sinr * math.sin(angle) * radius.imag + self.center.real
+        y = sinr * math.cos(angle) * radius.real + cosr * math.sin(angle) * radius.imag + self.center.imag
+        return complex(x, y)
+
+    def length(self):
+        if self.start == self.end:
+            return 0.0
+        if self.radius.real == 0 or self.radius.imag == 0:
+            return abs(self.end - self.start)
+        if self.radius.real == self.radius.imag:   # circular: radius x swept angle
+            return abs((self.radius.real * self.radius_scale) * self.delta * math.pi / 180)
+        return _segment_length(self, 0.0, 1.0, self.point(0), self.point(1), 0)
+
+
 def _segment_length(curve, start, end, start_point, end_point, depth):
     """Recursive chord subdivision until two half-chords add < 1e-12 to one chord."""
     mid = (start + end) / 2
@@ -151,7 +223,7 @@ _NUM_RE = re.compile(r"[-+]?(?:\d+\.?\d*|\.\d+)(?:[eE][-+]?\d+)?")
 
 
 def parse_svg_path(d: str) -> list:
-    """``d`` attribute -> list of segments (Move / Line / Cubic / Quad / closing Line)."""
+    """``d`` attribute -> list of segments (Move / Line / Cubic / Quad / Arc / closing Line)."""
     tokens = _CMD_RE.split(d)
     segments: list = []
     cur = 0j
@@ -170,8 +242,6 @@ def parse_svg_path(d: str) -> list:
             cur = start
             last_cmd, last_ctrl = c, None
             continue
-        if c == "A":
-            raise NotImplementedError("elliptical arcs are not used by the reference tracks")
         k = 0
         first = True
         while k < len(nums):
@@ -214,6 +284,13 @@ def parse_svg_path(d: str) -> list:
                 if rel:
                     c1, e = cur + c1, cur + e
                 segments.append(_Quad(cur, c1, e)); cur = e; last_ctrl = c1
+            elif c == "A":
+                radius = complex(nums[k], nums[k + 1]); rotation = nums[k + 2]
+                large, sweep = nums[k + 3], nums[k + 4]
+                e = complex(nums[k + 5], nums[k + 6]); k += 7
+                if rel:
+                    e = cur + e
+                segments.append(_Arc(cur, radius, rotation, large, sweep, e)); cur = e; last_ctrl = None
             elif c == "T":
                 e = complex(nums[k], nums[k + 1]); k += 2
                 if rel:
@@ -406,3 +483,81 @@ def load_track(name: str) -> Track:
         raise FileNotFoundError(f"no bundled track blob {p}; build one with tools/make_track_blobs.py "
                                 f"or ft_grandprix_amd.track.load_track_from_template()")
     return Track.load_npz(p)
+
+
+# ----------------------------------------------------------------------------
+# Command line: the reference's ``python -m ft_grandprix.chunk`` (chunk.py:10-98), plus the track blob
+# ----------------------------------------------------------------------------
+
+def write_chunks(image_path: str, output_dir: str = "rendered/chunks", chunk_width: int = CHUNK_PX, chunk_height: int = CHUNK_PX,
+                 verbose: bool = True, scale: float = 1, force: bool = False) -> Optional[dict]:
+    """The files ``chunk()`` leaves behind (chunk.py:10-79): one ``IIIxJJJ.png`` per tile that holds a wall pixel -- walls white,
+    everything else black -- and ``metadata.json``.  Same refusals: a non-empty output directory is only replaced with
+    ``force`` and only if it carries a ``metadata.json`` (i.e. looks like ours)."""
+    import shutil
+    import sys
+    from PIL import Image
+    parent = os.path.dirname(output_dir)
+    if parent and not os.path.isdir(parent):
+        os.makedirs(parent)
+    if os.path.exists(output_dir):
+        existing = os.listdir(output_dir)
+        if len(existing) != 0:
+            if not force:
+                print(f"Refusing to overwrite existing directory `{output_dir}`", file=sys.stderr)
+                return None
+            if verbose:
+                print(f"`{output_dir}` exists but the force option was specified", file=sys.stderr)
+            if "metadata.json" not in existing:
+                print("Refusing to overwrite directory without a `metadata.json` (we may not have created it)")
+                return None
+        if verbose:
+            print(f"Removing `{output_dir}`")
+        shutil.rmtree(output_dir)
+    os.mkdir(output_dir)
+    wall = threshold_image(Image.open(image_path))
+    name = ".".join(os.path.basename(image_path).split(".")[:-1])
+    meta = chunk_metadata(wall, name, scale, chunk_width, chunk_height)
+    kept = {(i, j) for i, j in meta["chunks"]}
+    rgb = np.repeat((wall.astype(np.uint8) * 255)[:, :, None], 3, axis=2)
+    for i in range(meta["horizontal_chunks"]):
+        for j in range(meta["vertical_chunks"]):
+            base = f"{i:03}x{j:03}.png"
+            if (i, j) in kept:
+                if verbose:
+                    print(f"Going to produce non-empty chunk {base}")
+                tile = rgb[j * chunk_height:(j + 1) * chunk_height, i * chunk_width:(i + 1) * chunk_width]
+                Image.fromarray(np.ascontiguousarray(tile)).save(os.path.join(output_dir, base))
+            elif verbose:
+                print(f"Not going to produce empty chunk {base}")
+    with open(os.path.join(output_dir, "metadata.json"), "w") as f:
+        json.dump(meta, f)
+    return meta
+
+
+def main(argv=None) -> int:
+    import argparse
+    ap = argparse.ArgumentParser(prog="python -m ft_grandprix_amd.track",
+                                 description="chunk a track image like ft_grandprix.chunk; with --svg/--blob also build the track blob for ftgp_create")
+    ap.add_argument("-i", dest="input", required=True, help="the image file split into chunks")
+    ap.add_argument("-o", dest="output", default="rendered/chunks", help="the output directory chunks")
+    ap.add_argument("-W", dest="chunk_width", default=CHUNK_PX, type=int, help="the chunk width to use in pixels")
+    ap.add_argument("-H", dest="chunk_height", default=CHUNK_PX, type=int, help="the chunk height to use in pixels")
+    ap.add_argument("-v", dest="verbose", action="store_true", help="verbose output")
+    ap.add_argument("-f", dest="force", action="store_true", help="overwrite any directory")
+    ap.add_argument("--svg", help="centre-line SVG (<name>-path.svg): also sample the 100 path points")
+    ap.add_argument("--blob", help="write the track blob (.npz) consumed by ft_grandprix_amd.track.Track.load_npz / capi.Env")
+    a = ap.parse_args(argv)
+    write_chunks(a.input, a.output, a.chunk_width, a.chunk_height, a.verbose, force=a.force)
+    if a.blob:
+        from PIL import Image
+        if not a.svg:
+            ap.error("--blob needs --svg")
+        name = ".".join(os.path.basename(a.input).split(".")[:-1])
+        t = build_track(threshold_image(Image.open(a.input)), extract_path_from_svg(a.svg), name)
+        t.save_npz(a.blob)
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

@@ -41,7 +41,7 @@ extern "C" {
 #define FTGP_POLICY_RANDOM    4  /* counter-based RNG keyed (seed, car, step): speed~U(0,3), steer~U(-1,1) */
 
 #define FTGP_PATH_POINTS   100   /* ft_grandprix/curve.py:8 */
-#define FTGP_MAX_LAP_TIMES  16   /* lap times kept per car (oldest kept; lap_target default is 10, custom.py:961) */
+#define FTGP_MAX_LAP_TIMES  32   /* lap times kept per car (the oldest are kept; VehicleState.times is unbounded, lap_target defaults to 10, custom.py:124,961) */
 
 /* number of doubles / ints per car in the packed read-back rows */
 #define FTGP_SNAPSHOT_DOUBLES 10 /* laps, vel[3], yaw, pitch, roll, lap_completion, absolute_completion, time */

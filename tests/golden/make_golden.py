@@ -12,6 +12,10 @@ Fixtures (data only -- inputs and the reference's outputs):
                    lap_completion / absolute_completion truth table, ordinal()
   g5_progress.npz  the lap-progress block custom.py:1340-1372 executed verbatim (sliced from the source text
                    and exec'd against stub objects) on hand-built position traces
+  g6_chunk_cli.json  ft_grandprix.chunk.chunk() on a generated 130 x 95 image with -W 20 -H 20 and 32 x 24 tiles:
+                   metadata.json, the list of files written and the SHA-256 of every tile's decoded RGB pixels
+  g7_bracket.json  ft_grandprix.bracket.Hasher(10).hash on sample strings; compute_driver_files() on a generated drivers
+                   directory (the palette it used is stored as the function's input)
 
 custom.py imports mujoco / dearpygui / empy / svg.path, which are not installed; they are replaced by
 MagicMock entries in sys.modules for the import only -- none of the functions
@@ -28,7 +32,7 @@ from unittest import mock
 
 import numpy as np
 
-REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
+REF = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("--") else "/root/reference"
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REF)
 sys.path.insert(0, os.path.join(HERE, "..", ".."))
@@ -256,7 +260,79 @@ def gen_g5():
     np.savez_compressed(os.path.join(HERE, "g5_progress.npz"), **data)
 
 
+# ----------------------------------------------------------------------------- G6
+def g6_image():
+    """Deterministic test image: white curves and blobs on black, plus off-white and coloured pixels that must NOT count as wall."""
+    rng = np.random.default_rng(6)
+    h, w = 95, 130
+    img = np.zeros((h, w, 3), dtype=np.uint8)
+    yy, xx = np.mgrid[0:h, 0:w]
+    ring = np.abs(np.hypot(xx - 60, yy - 45) - 30) < 1.2
+    img[ring] = 255
+    img[10:14, 100:128] = 255
+    img[rng.random((h, w)) < 0.01] = (255, 255, 254)          # almost white: not a wall (chunk.py:41)
+    img[rng.random((h, w)) < 0.01] = (255, 0, 0)
+    img[80:95, 0:3] = 255                                       # touches the ragged last row of tiles
+    return img
+
+
+def gen_g6():
+    from PIL import Image
+    out = {"cases": []}
+    with tempfile.TemporaryDirectory() as td:
+        cwd = os.getcwd(); os.chdir(td)
+        try:
+            Image.fromarray(g6_image()).save("g6.png")
+            Image.fromarray(g6_image()).save(os.path.join(HERE, "g6_input.png"))      # the input travels with the fixture
+            for cw, chh in ((20, 20), (32, 24)):
+                ref_chunk.chunk("g6.png", output_dir="rendered/chunks", chunk_width=cw, chunk_height=chh, verbose=False, scale=2.0, force=True)
+                meta = json.load(open("rendered/chunks/metadata.json"))
+                files = sorted(os.listdir("rendered/chunks"))
+                sha = {f: hashlib.sha256(np.asarray(Image.open(os.path.join("rendered/chunks", f)).convert("RGB")).tobytes()).hexdigest()
+                       for f in files if f.endswith(".png")}
+                out["cases"].append({"chunk_width": cw, "chunk_height": chh, "metadata": meta, "files": files, "tile_sha256": sha})
+            # refusal semantics (chunk.py:23-34): a foreign non-empty directory is never replaced
+            os.makedirs("foreign"); open("foreign/keep.txt", "w").write("x")
+            ref_chunk.chunk("g6.png", output_dir="foreign", verbose=False, force=True)
+            out["foreign_after_force"] = sorted(os.listdir("foreign"))
+            ref_chunk.chunk("g6.png", output_dir="rendered/chunks", verbose=False, force=False)
+            out["existing_after_noforce"] = sorted(os.listdir("rendered/chunks")) == out["cases"][-1]["files"]
+        finally:
+            os.chdir(cwd)
+    json.dump(out, open(os.path.join(HERE, "g6_chunk_cli.json"), "w"))
+    print("g6:", [(c["chunk_width"], len(c["files"])) for c in out["cases"]], out["foreign_after_force"], out["existing_after_noforce"])
+
+
+# ----------------------------------------------------------------------------- G7
+def gen_g7():
+    from ft_grandprix import bracket as ref_bracket
+    from ft_grandprix.colors import colors as ref_colors
+    strings = ["", "a", "drivers.template", "drivers.template.", "ft_grandprix.nidc", "x" * 40, "drivers.Zeta9", "drivers.my_driver"]
+    hashes = {s: ref_bracket.Hasher(10).hash(s) for s in strings}
+    hashes_seed3 = {s: ref_bracket.Hasher(3).hash(s) for s in strings}
+    palette = [a[1] for a in sorted(list(ref_colors.items()), key=lambda t: t[0])]      # what compute_driver_files indexes into
+    names = ["alpha.py", "beta_driver.py", "__init__.py", "notes.txt", "gamma.py", "zz_top.pyc"]
+    with tempfile.TemporaryDirectory() as td:
+        cwd = os.getcwd(); os.chdir(td)
+        try:
+            os.makedirs("drivers")
+            for n in names:
+                open(os.path.join("drivers", n), "w").write("# generated\n")
+            ref_bracket.compute_driver_files("drivers", silent=True)
+            written = sorted(f for f in os.listdir("drivers") if f.endswith(".json"))
+            items = {f: json.load(open(os.path.join("drivers", f))) for f in written}
+        finally:
+            os.chdir(cwd)
+    json.dump({"hash_seed10": hashes, "hash_seed3": hashes_seed3, "palette": palette, "files": names, "written": written, "items": items},
+              open(os.path.join(HERE, "g7_bracket.json"), "w"))
+    print("g7:", hashes, written)
+
+
 if __name__ == "__main__":
+    gen_g6()
+    gen_g7()
+    if "--only-new" in sys.argv:
+        raise SystemExit(0)
     gen_g1()
     gen_g2()
     gen_g3()

@@ -238,6 +238,22 @@ def test_enlarged_vehicle_box_is_seen(product, oracle):
         assert_same_state(g, o)
 
 
+def test_user_track_from_png_and_svg_on_gpu(product, oracle, tmp_path):
+    """f-2 end to end: a generated PNG + SVG centre-line (H V L A Q C S commands) in the reference's template layout ->
+    load_track_from_template -> ftgp_create -> sweep and closed loop, GPU vs oracle (a 640 x 480 image: 32 x 24 chunks)."""
+    from ft_grandprix_amd.track import load_track_from_template
+    from tests.helpers import write_template_track
+    write_template_track(str(tmp_path), "generated")
+    t = load_track_from_template(str(tmp_path), "generated")
+    g, o = both(product, oracle, t, n_envs=40, n_rays=1080, spawn_mode=1, seed=3, lap_target=2)
+    with g, o:
+        g.step(1); o.step(1)
+        np.testing.assert_array_equal(g.lidar(), o.lidar())
+        assert (g.lidar() > 0).mean() > 0.99
+        g.rollout("fast", 500); o.rollout("fast", 500)
+        assert_same_state(g, o)
+
+
 def test_multi_car_env_config5(product, oracle):
     """Config 5: 4 cars per env share a world -- inter-vehicle rays and car-car contact."""
     t = load_track("track")

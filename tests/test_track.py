@@ -43,8 +43,6 @@ def test_svg_path_semantics():
     # smooth cubic reflects the previous control point
     seg = tr.parse_svg_path("M 0,0 C 0,5 5,5 5,0 S 10,-5 10,0")
     assert seg[2].c1 == complex(5, -5)
-    with pytest.raises(NotImplementedError):
-        tr.parse_svg_path("M 0,0 A 5,5 0 0 1 10,10")
 
 
 def test_cubic_length_matches_fine_polyline():
@@ -73,3 +71,90 @@ def test_synthetic_oval_runs_through_the_oracle(oracle):
         e.rollout("nidc", 400)
         r = e.lidar()
         assert (r > 0).mean() > 0.95 and np.abs(e.pose()[:, 7:9]).max() > 0.3
+
+
+# ---------------------------------------------------------------- elliptical arcs, CLI (fixture G6), bracket (fixture G7)
+def test_svg_elliptical_arcs():
+    # half circle of radius 5 from (0,0) to (10,0): length pi*5, midpoint at (5, -5) or (5, 5) by the sweep flag
+    seg = tr.parse_svg_path("M 0,0 A 5,5 0 0 1 10,0")
+    assert type(seg[1]).__name__ == "_Arc" and seg[1].length() == pytest.approx(np.pi * 5)
+    m = seg[1].point(0.5)
+    np.testing.assert_allclose([m.real, m.imag], [5, -5], atol=1e-12)
+    m = tr.parse_svg_path("M 0,0 A 5,5 0 0 0 10,0")[1].point(0.5)
+    np.testing.assert_allclose([m.real, m.imag], [5, 5], atol=1e-12)
+    # radii too small for the chord are scaled up (SVG implementation notes F.6.6)
+    a = tr.parse_svg_path("M 0,0 a 1,1 0 0 1 10,0")[1]
+    assert a.radius_scale == pytest.approx(5.0) and a.length() == pytest.approx(np.pi * 5)
+    # a rotated ellipse: the arc ends where it should and its length matches a fine polyline
+    e = tr.parse_svg_path("M 10,20 A 30,12 25 1 0 40,45")[1]
+    t = np.linspace(0, 1, 20001)
+    z = np.array([e.point(x) for x in t])
+    assert abs(z[0] - (10 + 20j)) < 1e-9 and abs(z[-1] - (40 + 45j)) < 1e-9
+    assert e.length() == pytest.approx(np.abs(np.diff(z)).sum(), rel=1e-6)
+    # degenerate forms
+    assert tr.parse_svg_path("M 0,0 A 0,5 0 0 1 3,4")[1].length() == pytest.approx(5.0)
+    assert tr.parse_svg_path("M 1,1 A 5,5 0 0 1 1,1")[1].length() == 0.0
+
+
+def test_g6_chunk_cli_matches_the_reference(tmp_path):
+    """python -m ft_grandprix_amd.track against ft_grandprix.chunk.chunk() (fixture G6: files, metadata.json, tile pixels)."""
+    import hashlib, json, os, subprocess, sys
+    from PIL import Image
+    from tests.helpers import golden, ROOT
+    g = json.load(open(golden("g6_chunk_cli.json")))
+    out = str(tmp_path / "rendered" / "chunks")
+    for case in g["cases"]:
+        r = subprocess.run([sys.executable, "-m", "ft_grandprix_amd.track", "-i", golden("g6_input.png"), "-o", out, "-f",
+                            "-W", str(case["chunk_width"]), "-H", str(case["chunk_height"])], cwd=ROOT, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert sorted(os.listdir(out)) == case["files"]
+        meta = json.load(open(os.path.join(out, "metadata.json")))
+        ref = dict(case["metadata"], name="g6_input", scale=meta["scale"])      # the fixture image was called g6.png; scale is a caller argument
+        assert meta == ref
+        for f, sha in case["tile_sha256"].items():
+            px = np.asarray(Image.open(os.path.join(out, f)).convert("RGB"))
+            assert hashlib.sha256(px.tobytes()).hexdigest() == sha, f
+    # refusal semantics of chunk.py:23-34
+    foreign = tmp_path / "foreign"; foreign.mkdir(); (foreign / "keep.txt").write_text("x")
+    assert tr.write_chunks(golden("g6_input.png"), str(foreign), verbose=False, force=True) is None
+    assert sorted(os.listdir(foreign)) == g["foreign_after_force"]
+    assert tr.write_chunks(golden("g6_input.png"), out, verbose=False, force=False) is None
+    assert sorted(os.listdir(out)) == g["cases"][-1]["files"]
+
+
+def test_g7_bracket_matches_the_reference(tmp_path):
+    """Hasher and compute_driver_files against the reference's outputs (fixture G7)."""
+    import json, os
+    from ft_grandprix_amd import bracket
+    from tests.helpers import golden
+    g = json.load(open(golden("g7_bracket.json")))
+    for seed, table in ((10, g["hash_seed10"]), (3, g["hash_seed3"])):
+        for s, h in table.items():
+            assert bracket.Hasher(seed).hash(s) == h, s
+    d = tmp_path / "drivers"; d.mkdir()
+    for n in g["files"]:
+        (d / n).write_text("# generated\n")
+    items = bracket.compute_driver_files(str(d), silent=True, palette=g["palette"])
+    written = sorted(f for f in os.listdir(d) if f.endswith(".json"))
+    assert written == g["written"]
+    for f in written:
+        assert json.load(open(d / f)) == g["items"][f]
+    assert [i["driver"] for i in items] == [g["items"][f]["driver"] for f in written]
+    # the default palette: CSS names, sorted; indices come from the same hash
+    it = bracket.compute_driver_files(str(d), silent=True, output_dir=str(tmp_path))
+    pal = bracket.default_palette()
+    assert it[0]["primary"] == pal[bracket.Hasher(10).hash("drivers.alpha") % len(pal)]
+
+
+def test_user_track_from_png_and_svg_through_the_oracle(oracle, tmp_path):
+    """f-2 end to end on the CPU: PNG + SVG (H V L A Q C S commands) -> load_track_from_template -> world -> cars drive."""
+    from ft_grandprix_amd import capi
+    from tests.helpers import write_template_track
+    wall = write_template_track(str(tmp_path), "generated")
+    t = tr.load_track_from_template(str(tmp_path), "generated")
+    np.testing.assert_array_equal(t.wall_mask(), wall)                     # off-white pixels are not walls
+    assert t.path.shape == (100, 2) and (t.hc, t.vc) == (32, 24)
+    np.testing.assert_allclose(t.path[0], [120 / 640 * 40, -80 / 480 * 40])   # group transform ignored (curve.py:13-16), custom.py:1185-1186
+    with capi.Env(oracle, t, n_envs=6, n_rays=90, spawn_mode=1, seed=3) as e:
+        e.rollout("nidc", 600)
+        assert (e.lidar() > 0).mean() > 0.95 and np.abs(e.pose()[:, 7:9]).max() > 0.3
