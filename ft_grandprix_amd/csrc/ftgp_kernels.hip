@@ -48,6 +48,9 @@ struct Lds {
 // step, so loads of constants (vehicle parameters, centre-line, ...) are never hoisted out of the loop -- hoisted, they
 // would stay live across the sweep and end up in scratch memory under the 64-VGPR budget.
 __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+s"(v)); return v; }
+// the lane index, recomputed where it is used: values derived from it (per-lane addresses, selects) then stay local to the phase
+// that needs them instead of being hoisted in front of the step loop and carried -- spilled -- across the sweep
+__device__ __forceinline__ int lane_here() { int l = lane_id(); asm volatile("" : "+v"(l)); return l; }
 
 struct LdsOffsets { int params, veh, path, ray, cars, frame, steps, scan, list, pool, k1; };
 
@@ -168,7 +171,7 @@ __device__ __forceinline__ void lidar_pool(const DeviceParams& P, const Lds& L, 
     const float r0 = sgpr((float)L.veh->v.lidar_ring_radius);
     const global_u8 field = (global_u8)uniform_ptr(P.field);
     const global_f32 ranges = (global_f32)uniform_ptr(P.ranges) + (size_t)ci0 * stride;
-    const int lane = lane_id();
+    const int lane = lane_here();
 
     FtgpRay ray; ftgp_ray_park(ray, -1.0f);
     float dxw = 0.0f, dyw = 0.0f;
@@ -433,7 +436,7 @@ __device__ __forceinline__ Force wall_term(const DeviceParams& P, const FtgpVehi
 }
 
 // Circles of this car against the circles of the other cars of the env (penalty spring/damper, pre-step states).
-__device__ __forceinline__ void car_contact(const DeviceParams& P, const FtgpVehicle& v, const CarCore* me, double ch, double sh,
+static __device__ __attribute__((noinline)) void car_contact(const DeviceParams& P, const FtgpVehicle& v, const CarCore* me, double ch, double sh,
                                             const CarCore* env_cars, int my_slot, Force& f)
 {
     const double r2 = 2.0 * v.contact_radius;
@@ -494,7 +497,7 @@ __device__ __forceinline__ void frame_write(const DeviceParams& P, const FtgpVeh
 template <bool MULTI>
 __device__ __forceinline__ void dynamics_lanes(const DeviceParams& P, const Lds& L, LidarFrame* next_frames, int ncars_here, int ci0)
 {
-    const int lane = lane_id();
+    const int lane = lane_here();
     const int c = lane >> 2, r = lane & 3;
     const bool on = c < ncars_here;
     CarCore* st = L.cars + (on ? c : 0);
@@ -635,7 +638,7 @@ static __device__ __attribute__((noinline)) int cover_count(double width, double
 // samples of each disparity and only recomputes the count when an earlier extension has changed them.
 __device__ __forceinline__ void policy_disparity(const DeviceParams& P, float* __restrict__ scan, CarCore* st, bool fast, int* __restrict__ list)
 {
-    const int lane = lane_id();
+    const int lane = lane_here();
     const int n = P.n_rays;
     const double car_width = fast ? 0.06 : 0.12;                    // fast.py:4 / nidc.py:5
     const double rpp = (2 * M_PI) / (double)n;                      // nidc.py:121
