@@ -147,22 +147,37 @@ struct FtgpStep { float sn; int t, cur, hi, xe, ye; bool stepx, done; };
 // landing point is within `eps` of a pixel boundary: the caller then runs ftgp_ray_fix() before ftgp_ray_commit().
 FTGP_HD bool ftgp_ray_step(FtgpRay& r, uint32_t w, float eps, FtgpStep& st)
 {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // same arithmetic, spelled with the gfx9 forms the compiler does not pick by itself: byte operands straight out of the
+    // entry (SDWA), floor-and-convert in one instruction, hardware fract, three-operand median for the clamp
+    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(st.xe) : "v"(r.ix), "v"(w));
+    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(st.ye) : "v"(r.iy), "v"(w));
+    st.done = st.xe == r.ix;                                  // kx == 0: wall or ring cell
+#else
     const int kx = (int)(w & 255u), ky = (int)(w >> 8);
     st.done = kx == 0;                                        // wall or ring cell
-    r.result = (w == 0u) ? fabsf(r.s) : r.result;             // |s|: a ray that starts on a boundary can produce -0
     st.xe = r.ix + kx; st.ye = r.iy + ky;
+#endif
+    r.result = (w == 0u) ? fabsf(r.s) : r.result;             // |s|: a ray that starts on a boundary can produce -0
     const float sX = ((float)st.xe - r.pum) * r.ivx;
     const float sY = ((float)st.ye - r.pvm) * r.ivy;
     st.stepx = sX < sY;
     st.sn = st.stepx ? sX : sY;
     const float tp = st.stepx ? r.pvm : r.pum, td = st.stepx ? r.dvm : r.dum;
     const float v = fmaf(td, st.sn, tp);
+    st.cur = st.stepx ? r.iy : r.ix; st.hi = (st.stepx ? st.ye : st.xe) - 1;
+#if defined(__HIP_DEVICE_COMPILE__)
+    int t;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(t) : "v"(v));
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(st.t) : "v"(t), "v"(st.cur), "v"(st.hi));       // clamp: cur <= hi always
+    const float frac = __builtin_amdgcn_fractf(v);            // v - floor(v), kept below 1: only ever compared with eps and 1 - eps
+#else
     const float fl = floorf(v);
     int t = (int)fl;
-    st.cur = st.stepx ? r.iy : r.ix; st.hi = (st.stepx ? st.ye : st.xe) - 1;
     t = t < st.cur ? st.cur : t; t = t > st.hi ? st.hi : t;
     st.t = t;
     const float frac = v - fl;
+#endif
     return !st.done & (fabsf(frac - 0.5f) > 0.5f - eps);    // within eps of a boundary (and never for a NaN)
 }
 
