@@ -162,6 +162,7 @@ __device__ __forceinline__ void lidar_pool(const DeviceParams& P, const Lds& L, 
     typedef const __attribute__((address_space(1))) unsigned char* global_u8;
     typedef const __attribute__((address_space(1))) uint16_t* global_u16;
     typedef __attribute__((address_space(1))) float* global_f32;
+    typedef __attribute__((address_space(1))) unsigned char* global_u8w;
     // wave-uniform constants of the sweep, pinned in SGPRs (they come out of the LDS parameter block, i.e. out of VGPRs)
     const int R = sgpr(P.n_rays), total = ncars_here * R;
     const int W = sgpr(P.width), H = sgpr(P.height), fstride = sgpr(P.fstride), stride = sgpr(P.ranges_stride);
@@ -205,7 +206,7 @@ __device__ __forceinline__ void lidar_pool(const DeviceParams& P, const Lds& L, 
                         if (rc < INFINITY && (r < 0.0f || rc < r)) r = rc;
                     }
             }
-            ranges[__mul24(c, stride) + j] = r;
+            *(global_f32)((global_u8w)ranges + ((uint32_t)(__mul24(c, stride) + j) << 2)) = r;      // SGPR base + 32-bit lane offset
             if (scan_lds) {          // the on-device driver only reads ranges[0] and ranges[eighth : n - eighth]
                 float* row = scan_rows + __mul24(c, win_floats);
                 const int jw = j - eighth;
@@ -234,7 +235,7 @@ __device__ __forceinline__ void lidar_pool(const DeviceParams& P, const Lds& L, 
             }
             if (done && base + rank < total) {
                 cj = (c << 16) | j;
-                const float4 f4 = *reinterpret_cast<const float4*>(frames + c);      // u0, v0, chf, shf
+                const float4 f4 = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(frames) + __mul24(c, (int)sizeof(LidarFrame)));   // u0, v0, chf, shf
                 const float2 bd = L.ray[j];
                 dxw = fmaf(f4.z, bd.x, -(f4.w * bd.y));
                 dyw = fmaf(f4.w, bd.x, f4.z * bd.y);

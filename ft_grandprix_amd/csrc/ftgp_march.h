@@ -113,9 +113,16 @@ FTGP_HD void ftgp_ray_park(FtgpRay& r, float result)
 // ivx, ivy = |1 / du|, |1 / dv| correctly rounded (IEEE division; +inf where the direction is 0: that axis is never stepped)
 FTGP_HD void ftgp_ray_init(FtgpRay& r, float pu, float pv, float du, float dv, float ivx, float ivy, int W, int H, int fstride, uint32_t plane256)
 {
+#if defined(__HIP_DEVICE_COMPILE__)
+    int ix0, iy0;                                             // floor and convert in one instruction; the conversion saturates
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ix0) : "v"(pu));
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(iy0) : "v"(pv));
+    const bool inside = !__builtin_isunordered(pu, pv) && (unsigned)ix0 < (unsigned)W && (unsigned)iy0 < (unsigned)H;   // a NaN converts to 0: test it
+#else
     const float fx = floorf(pu), fy = floorf(pv);
     const bool inside = fx >= 0.0f && fx < (float)W && fy >= 0.0f && fy < (float)H;
     const int ix0 = (int)fx, iy0 = (int)fy;
+#endif
     const bool mx = du < 0.0f, my = dv < 0.0f;
     const float adu = fabsf(du), adv = fabsf(dv);
     const bool ydom = !(adu >= adv);
@@ -127,7 +134,11 @@ FTGP_HD void ftgp_ray_init(FtgpRay& r, float pu, float pv, float du, float dv, f
     if (FTGP_SECTORS == 16) sector |= (2.0f * (ydom ? adu : adv) > (ydom ? adv : adu)) ? 8u : 0u;      // slope minor / major above 1/2
     r.mx = mx ? -1 : 0; r.my = my ? -1 : 0;
     r.ix = ix0 ^ r.mx; r.iy = iy0 ^ r.my;
+    #if defined(__HIP_DEVICE_COMPILE__)
+    r.offC = (int)((__umul24(sector, plane256) << 8) + 2u * (uint32_t)(fstride + 1));       // plane256 < 2^24
+#else
     r.offC = (int)(((sector * plane256) << 8) + 2u * (uint32_t)(fstride + 1));
+#endif
     if (!inside) { r.ix = r.iy = 0; r.offC = 0; r.mx = r.my = 0; }       // starts off the image: ring cell (0, 0), result stays -1
 }
 
