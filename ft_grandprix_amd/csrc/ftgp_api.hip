@@ -72,7 +72,7 @@ struct FtgpEnv {
     bool timed = false;
     // device buffers
     uint16_t* d_field = nullptr; uint32_t* d_bits = nullptr; uint32_t* d_nearbits = nullptr;
-    double* d_path = nullptr; double* d_spawn = nullptr; float* d_ray = nullptr; void* d_veh = nullptr; DeviceParams* d_params = nullptr;
+    double* d_path = nullptr; double* d_spawn = nullptr; float* d_ray = nullptr; float* d_cover = nullptr; void* d_veh = nullptr; DeviceParams* d_params = nullptr;
     CarState* d_cars = nullptr; float* d_ranges = nullptr; int64_t* d_steps = nullptr;
     uint8_t* d_env_mask = nullptr; uint8_t* d_car_mask = nullptr; double* d_ctrl = nullptr; double* d_pose = nullptr;
     double* d_metrics = nullptr; double* d_gather = nullptr;
@@ -152,6 +152,30 @@ void build_tables(const FtgpTrack& t, int reach, HostTables& g)
 
 inline int pad16(size_t n) { return (int)((n + 15) & ~(size_t)15); }
 
+// nidc.py:57,93-99 exactly as the driver evaluates it (binary64, libm): points covered by a disparity whose closer sample is d
+int cover_count_host(double width, double rpp, double close_dist)
+{
+    const double angle = 2 * atan(width / (2 * close_dist));
+    const double cnt = ceil(angle / rpp);
+    return (cnt > 2147483000.0) ? 2147483000 : (cnt < -2147483000.0 ? -2147483000 : (int)cnt);
+}
+
+// thr[k], k = 1 .. kmax: the largest positive binary32 sample whose count is still >= k (the count never increases with the
+// sample); thr[0] = the count of a sample of exactly 0.  Found by bisection over the bit patterns of the positive floats.
+void build_cover_table(double car_width, int n_rays, int kmax, float* thr)
+{
+    const double width = (car_width / 2) * (1 + 300.0 / 100);       // nidc.py:93
+    const double rpp = (2 * M_PI) / (double)n_rays;                 // nidc.py:121
+    auto num = [&](uint32_t bits) { float f; memcpy(&f, &bits, 4); return cover_count_host(width, rpp, (double)f); };
+    thr[0] = (float)cover_count_host(width, rpp, 0.0);
+    for (int k = 1; k <= kmax; ++k) {
+        uint32_t lo = 1u, hi = 0x7f7fffffu;                         // num(lo) >= k by the choice of kmax; num(hi) may be < k
+        if (num(hi) >= k) { memcpy(&thr[k], &hi, 4); continue; }
+        while (hi - lo > 1) { const uint32_t mid = lo + (hi - lo) / 2; if (num(mid) >= k) lo = mid; else hi = mid; }
+        memcpy(&thr[k], &lo, 4);
+    }
+}
+
 // LDS layout for `cpb` cars and `wpb` waves per workgroup; returns the total
 int lds_layout(DeviceParams& P, int cpb, int wpb)
 {
@@ -167,6 +191,7 @@ int lds_layout(DeviceParams& P, int cpb, int wpb)
     P.off_list = o;   o += wpb * FTGP_WAVE * (int)sizeof(int);
     P.off_pool = o;   o += 16;
     P.off_k1 = o;     o += FTGP_MAX_CARS_PER_BLOCK * (FTGP_FORCE_TERMS * 24 + 4 * 8 + 104);      // K1 staging: force terms | new wheel spins | new state
+    P.off_cover = o;  o += pad16(sizeof(float) * (size_t)(P.cover_kmax + 1));             // cover-count thresholds of the launch's driver (last: its size = lds_bytes - off_cover)
     P.lds_bytes = o;
     P.cars_per_block = cpb; P.waves_per_block = wpb;
     return o;
@@ -263,7 +288,7 @@ int ftgp_destroy(FtgpEnv* e)
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->side) (void)hipStreamSynchronize(e->side);
     if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
-    void* bufs[] = { e->d_field, e->d_bits, e->d_nearbits, e->d_params, e->d_veh, e->d_path, e->d_spawn, e->d_ray, e->d_cars, e->d_ranges,
+    void* bufs[] = { e->d_field, e->d_bits, e->d_nearbits, e->d_cover, e->d_params, e->d_veh, e->d_path, e->d_spawn, e->d_ray, e->d_cars, e->d_ranges,
                      e->d_steps, e->d_env_mask, e->d_car_mask, e->d_ctrl, e->d_pose, e->d_metrics, e->d_gather, e->d_prog, e->d_core };
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (e->ev_start) (void)hipEventDestroy(e->ev_start);
@@ -341,6 +366,11 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
         P.contact_reach = std::max((int)ceil(rmax * P.inv_px_x), (int)ceil(rmax * P.inv_px_y));
     }
     P.eighth = (int)((double)cfg->n_rays / 8.0);                    // nidc.py:18
+    {   // the largest cover count any positive sample can produce (that of the smallest positive float), over both drivers
+        const double rpp = (2 * M_PI) / (double)cfg->n_rays;
+        const float tiny = 1.401298464e-45f;
+        P.cover_kmax = std::max(1, std::max(cover_count_host(0.24, rpp, (double)tiny), cover_count_host(0.12, rpp, (double)tiny)));
+    }
     P.win_floats = (1 + (cfg->n_rays - 2 * P.eighth) + 3) & ~3;
     P.snap_eps = ftgp_snap_eps(t.width, t.height);
     P.ray_magic = (uint32_t)((0x100000000ull + (uint64_t)cfg->n_rays - 1) / (uint64_t)cfg->n_rays);
@@ -430,6 +460,15 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
     CREATE_TRY(hipMalloc(&e->d_path, sz_path));
     CREATE_TRY(hipMalloc(&e->d_ray, sz_ray));
     CREATE_TRY(hipMalloc(&e->d_spawn, sizeof(double) * 4 * FTGP_PATH_POINTS));
+    {   // cover-count thresholds: nidc (car_width 0.12, nidc.py:5) then fast (0.06, fast.py:4), each padded to the staged size
+        const size_t stride = (size_t)P.cover_kmax + 1, padded = (size_t)pad16(sizeof(float) * stride) / sizeof(float);
+        std::vector<float> thr(stride + padded + 4, 0.0f);
+        build_cover_table(0.12, cfg->n_rays, P.cover_kmax, thr.data());
+        build_cover_table(0.06, cfg->n_rays, P.cover_kmax, thr.data() + stride);
+        CREATE_TRY(hipMalloc(&e->d_cover, sizeof(float) * thr.size()));
+        CREATE_TRY(hipMemcpy(e->d_cover, thr.data(), sizeof(float) * thr.size(), hipMemcpyHostToDevice));
+        P.cover_thr = e->d_cover;
+    }
     CREATE_TRY(hipMalloc(&e->d_cars, sizeof(CarState) * n_cars));
     CREATE_TRY(hipMalloc(&e->d_ranges, sizeof(float) * n_cars * P.ranges_stride));
     CREATE_TRY(hipMalloc(&e->d_steps, sizeof(int64_t) * (size_t)P.n_envs));

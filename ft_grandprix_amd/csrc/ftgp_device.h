@@ -54,7 +54,7 @@ struct DeviceParams {
     int32_t contact_reach;        // chessboard reach (pixels) of the wall-contact window; `nearbits` is the wall set dilated by it
     // step-kernel launch shape and LDS layout (byte offsets, all 16-B aligned)
     int32_t cars_per_block, waves_per_block, eighth, win_floats;   // win_floats: floats per LDS scan row = 1 + (n_rays - 2*eighth), padded to 4
-    int32_t off_params, off_veh, off_path, off_ray, off_cars, off_frame, off_steps, off_scan, off_list, off_pool, off_k1, lds_bytes;
+    int32_t off_params, off_veh, off_path, off_ray, off_cars, off_frame, off_steps, off_scan, off_list, off_pool, off_k1, off_cover, lds_bytes, cover_kmax;
     int32_t bubble_wrap, pad_b;   // custom.py:1041-1055: the four wheel softeners collide with the walls
     const uint16_t* field;        // [FTGP_SECTORS][height + 2][width + 2] box entries (ftgp_march.h), HBM/L2
     const uint32_t* bits;         // [height][words_per_row] wall bitmap
@@ -63,6 +63,7 @@ struct DeviceParams {
     const double* path;           // [100][2]
     const double* spawn;          // [100][4] x, y, qw, qz
     const float* ray_dir;         // [n_rays][2] body-frame ray directions (sin phi, -cos phi), binary32
+    const float* cover_thr;       // [2][cover_kmax + 1 (padded to 4)] cover-count thresholds of the nidc / fast drivers (cover_count)
     // state
     CarState* cars;
     float* ranges;                // [n_cars][ranges_stride]

@@ -42,6 +42,7 @@ struct Lds {
     Force* terms;             // [cars_per_block][FTGP_FORCE_TERMS] K1 staging: force terms in the order they are summed
     double* wnew;             // [cars_per_block][4] K1 staging: new wheel spins
     Dyn* next;                // [cars_per_block] K1 staging: new dynamic state before the commit
+    const float* cover;       // [cover_kmax + 1] cover-count thresholds of the launch's driver (see cover_count)
 };
 
 // A wave-uniform value the optimiser cannot see through.  The step loop rebuilds its LDS pointers from such offsets every
@@ -52,14 +53,14 @@ __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+s"(v)); retur
 // that needs them instead of being hoisted in front of the step loop and carried -- spilled -- across the sweep
 __device__ __forceinline__ int lane_here() { int l = lane_id(); asm volatile("" : "+v"(l)); return l; }
 
-struct LdsOffsets { int params, veh, path, ray, cars, frame, steps, scan, list, pool, k1; };
+struct LdsOffsets { int params, veh, path, ray, cars, frame, steps, scan, list, pool, k1, cover; };
 
 __device__ __forceinline__ LdsOffsets lds_offsets(const DeviceParams& P)
 {
     LdsOffsets o;
     o.params = sgpr(P.off_params); o.veh = sgpr(P.off_veh); o.path = sgpr(P.off_path); o.ray = sgpr(P.off_ray); o.cars = sgpr(P.off_cars);
     o.frame = sgpr(P.off_frame); o.steps = sgpr(P.off_steps); o.scan = sgpr(P.off_scan); o.list = sgpr(P.off_list); o.pool = sgpr(P.off_pool);
-    o.k1 = sgpr(P.off_k1);
+    o.k1 = sgpr(P.off_k1); o.cover = sgpr(P.off_cover);
     return o;
 }
 
@@ -79,6 +80,7 @@ __device__ __forceinline__ Lds lds_view(const LdsOffsets& o, unsigned char* lds)
     L.terms = reinterpret_cast<Force*>(k1);
     L.wnew = reinterpret_cast<double*>(k1 + FTGP_MAX_CARS_PER_BLOCK * FTGP_FORCE_TERMS * sizeof(Force));
     L.next = reinterpret_cast<Dyn*>(k1 + FTGP_MAX_CARS_PER_BLOCK * (FTGP_FORCE_TERMS * sizeof(Force) + 4 * sizeof(double)));
+    L.cover = reinterpret_cast<const float*>(lds + opaque(o.cover));
     return L;
 }
 
@@ -623,31 +625,36 @@ __device__ __forceinline__ void dynamics_lanes(const DeviceParams& P, const Lds&
 // =============================================================================================
 // K5: on-device drivers.  nidc.py:12-131 / fast.py:11-139 restated for one wave; the previous scan sits in LDS.
 // =============================================================================================
-// number of points one disparity covers: ceil(2 * atan(width / (2 * close_dist)) / radians_per_point), nidc.py:57,93-99
-// (kept out of line: the binary64 atan carries some twenty polynomial constants that would otherwise be hoisted into registers
-// around the driver's loops; internal linkage lets the callers' register budget apply to it)
-static __device__ __attribute__((noinline)) int cover_count(double width, double rpp, double close_dist)
+// Number of points one disparity covers: ceil(2 * atan(width / (2 * close_dist)) / radians_per_point), nidc.py:57,93-99.
+// close_dist is a binary32 sample and the count is a non-increasing step function of it, so the host tabulates -- with the
+// very expression above, in binary64 with libm -- the largest sample thr[k] that still yields a count >= k (ftgp_create,
+// build_cover_table).  The device then needs no atan: the count is the number of thresholds >= the sample.
+// thr[0] holds the count for a sample of exactly 0 (the division by zero of the reference), as a float.
+__device__ __forceinline__ int cover_count(const float* __restrict__ thr, int kmax, float close_dist)
 {
-    const double angle = 2 * atan(width / (2 * close_dist));
-    const double cnt = ceil(angle / rpp);
-    return (cnt > 2147483000.0) ? 2147483000 : (cnt < -2147483000.0 ? -2147483000 : (int)cnt);
+    if (!(close_dist > 0.0f)) return close_dist == 0.0f ? (int)thr[0] : 0;      // negative (no hit) or NaN: nothing to cover
+    int lo = 0, hi = kmax;                                                      // invariant: thr[lo] >= d (lo = 0: virtual) , thr[hi + 1] < d
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (thr[mid] >= close_dist) lo = mid; else hi = mid - 1;
+    }
+    return lo;
 }
 
 // scan: [0] = ranges[0], [1 ...] = ranges[eighth : n - eighth] (the copy the reference makes, nidc.py:19, is this LDS row).
 // Disparities are found on the unmodified scan (nidc.py:26-40) and extended in index order (nidc.py:86-105).  The cover
 // counts (one atan each) are prepared for up to 64 disparities at once, one per lane; the ordered pass re-reads the two
 // samples of each disparity and only recomputes the count when an earlier extension has changed them.
-__device__ __forceinline__ void policy_disparity(const DeviceParams& P, float* __restrict__ scan, CarCore* st, bool fast, int* __restrict__ list)
+__device__ __forceinline__ void policy_disparity(const DeviceParams& P, float* __restrict__ scan, CarCore* st, bool fast, int* __restrict__ list, const float* __restrict__ thr)
 {
     const int lane = lane_here();
     const int n = P.n_rays;
-    const double car_width = fast ? 0.06 : 0.12;                    // fast.py:4 / nidc.py:5
     const double rpp = (2 * M_PI) / (double)n;                      // nidc.py:121
     const int eighth = P.eighth;                                    // int(n / 8), nidc.py:18
     const int m = n - 2 * eighth;
     float* __restrict__ proc = scan + 1;
     const float range0 = scan[0];                                   // ranges[0], fast.py:135
-    const double width = (car_width / 2) * (1 + 300.0 / 100);       // nidc.py:93
+    const int kmax = P.cover_kmax;                                  // thr = the cover-count thresholds of this driver (width = (car_width / 2) * (1 + 300 / 100), nidc.py:93)
     // disparity flags: one ballot per 64 samples, parked in lane (pass); launch_steps() guarantees m <= 64 * 64
     uint64_t mymask = 0;
     const int npass = (m + FTGP_WAVE - 1) / FTGP_WAVE;
@@ -680,7 +687,7 @@ __device__ __forceinline__ void policy_disparity(const DeviceParams& P, float* _
         if (lane < nchunk) {
             index = list[lane];
             q0 = proc[index - 1]; q1 = proc[index];
-            num = cover_count(width, rpp, (double)((q1 < q0) ? q1 : q0));
+            num = cover_count(thr, kmax, (q1 < q0) ? q1 : q0);
         }
         wave_lds_sync();
         for (int d = 0; d < nchunk; ++d) {
@@ -692,7 +699,7 @@ __device__ __forceinline__ void policy_disparity(const DeviceParams& P, float* _
             const int close_idx = first + ((p1v < p0v) ? 1 : 0);   // argmin: first minimum
             const int far_idx = first + ((p1v > p0v) ? 1 : 0);     // argmax: first maximum
             const float ndf = (p1v < p0v) ? p1v : p0v;
-            if (!__all(same)) nn = cover_count(width, rpp, (double)ndf);
+            if (!__all(same)) nn = cover_count(thr, kmax, ndf);
             const bool cover_right = close_idx < far_idx;
             for (int i = lane; i < nn; i += FTGP_WAVE) {          // nidc.py:72-83, one target per lane
                 const int idx = cover_right ? close_idx + 1 + i : close_idx - 1 - i;
@@ -730,7 +737,7 @@ __device__ __forceinline__ void policy_disparity(const DeviceParams& P, float* _
 }
 
 // evaluates the driver of car ci and stores the controls into its state record
-__device__ __forceinline__ void policy_apply(const DeviceParams& P, int policy, float* scan, CarCore* st, int ci, int64_t steps, int* list)
+__device__ __forceinline__ void policy_apply(const DeviceParams& P, int policy, float* scan, CarCore* st, int ci, int64_t steps, int* list, const float* thr)
 {
     const bool lane0 = lane_id() == 0;
     if (st->finished) {                                             // finished cars get the null driver (custom.py:1446)
@@ -740,7 +747,7 @@ __device__ __forceinline__ void policy_apply(const DeviceParams& P, int policy, 
     switch (policy) {
     case FTGP_POLICY_LOBOTOMY: if (lane0) { st->u_speed = 0.0; st->u_steer = 0.0; } break;   // lobotomy.py:2-3
     case FTGP_POLICY_NIDC:
-    case FTGP_POLICY_FAST: policy_disparity(P, scan, st, policy == FTGP_POLICY_FAST, list); break;
+    case FTGP_POLICY_FAST: policy_disparity(P, scan, st, policy == FTGP_POLICY_FAST, list, thr); break;
     case FTGP_POLICY_RANDOM: {
         uint64_t h = splitmix64(P.seed + (uint64_t)((long)P.env_base * P.cars_per_env + ci) * 0x9E3779B97F4A7C15ull);
         h = splitmix64(h ^ (uint64_t)steps);
@@ -789,6 +796,8 @@ __global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(cons
     stage16(lds + Pg->off_veh, Pg->veh_dev, Pg->off_path - Pg->off_veh);
     stage16(lds + Pg->off_path, Pg->path, Pg->off_ray - Pg->off_path);
     stage16(lds + Pg->off_ray, Pg->ray_dir, Pg->off_cars - Pg->off_ray);
+    if (policy == FTGP_POLICY_NIDC || policy == FTGP_POLICY_FAST)
+        stage16(lds + Pg->off_cover, Pg->cover_thr + (policy == FTGP_POLICY_FAST ? Pg->cover_kmax + 1 : 0), Pg->lds_bytes - Pg->off_cover);
     __syncthreads();
     const LdsOffsets off = lds_offsets(P0);
     const int cpb = sgpr(P0.cars_per_block);
@@ -843,7 +852,7 @@ __global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(cons
         if (wave < ncars_here) __builtin_amdgcn_s_setprio(3);
 #endif
         for (int c = wave; c < ncars_here; c += nwaves) {
-            if (policy != FTGP_POLICY_HOST) policy_apply(P, policy, scan_prev + c * win_floats, L.cars + c, ci0 + c, L.steps[c], L.list + wave * FTGP_WAVE);
+            if (policy != FTGP_POLICY_HOST) policy_apply(P, policy, scan_prev + c * win_floats, L.cars + c, ci0 + c, L.steps[c], L.list + wave * FTGP_WAVE, L.cover);
             wave_lds_sync();
             int n = 0;
             if (lane == 0) n = atomicAdd(L.pool + 2 + par, 1);
@@ -904,7 +913,7 @@ __global__ void __launch_bounds__(256) ftgp_policy_kernel(DeviceParams P, int po
     if (lane < (int)(sizeof(CarCore) / 4))
         reinterpret_cast<uint32_t*>(st)[lane] = reinterpret_cast<const uint32_t*>(static_cast<const CarCore*>(&P.cars[ci]))[lane];
     wave_lds_sync();
-    policy_apply(P, policy, scan, st, ci, P.steps[ci / P.cars_per_env], list);
+    policy_apply(P, policy, scan, st, ci, P.steps[ci / P.cars_per_env], list, P.cover_thr + (policy == FTGP_POLICY_FAST ? P.cover_kmax + 1 : 0));
     wave_lds_sync();
     if (lane == 0) {
         P.cars[ci].u_speed = st->u_speed; P.cars[ci].u_steer = st->u_steer; P.cars[ci].last_steer = st->last_steer;
