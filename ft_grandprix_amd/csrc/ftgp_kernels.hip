@@ -655,15 +655,19 @@ __device__ __forceinline__ void policy_disparity(const DeviceParams& P, float* _
     float* __restrict__ proc = scan + 1;
     const float range0 = scan[0];                                   // ranges[0], fast.py:135
     const int kmax = P.cover_kmax;                                  // thr = the cover-count thresholds of this driver (width = (car_width / 2) * (1 + 300 / 100), nidc.py:93)
-    // disparity flags: one ballot per 64 samples, parked in lane (pass); launch_steps() guarantees m <= 64 * 64
+    // disparity flags (nidc.py:26-40, on the unmodified scan): lane l owns the contiguous samples [l * chunk, (l + 1) * chunk) and
+    // keeps its flags as bits of mymask; launch_steps() guarantees m <= 64 * 64, i.e. chunk <= 64
+    const int chunk = (m + FTGP_WAVE - 1) / FTGP_WAVE;
+    const int first = lane * chunk, end = min(m, first + chunk);
     uint64_t mymask = 0;
-    const int npass = (m + FTGP_WAVE - 1) / FTGP_WAVE;
-    for (int p = 0; p < npass; ++p) {
-        const int i = p * FTGP_WAVE + lane;
-        bool flag = false;
-        if (i >= 1 && i < m) flag = fabs((double)proc[i] - (double)proc[i - 1]) > 0.6;
-        const uint64_t b = __ballot(flag);
-        if (lane == p) mymask = b;
+    {
+        float prev = (first >= 1 && first < m) ? proc[first - 1] : 0.0f;
+        for (int i = first; i < end; ++i) {
+            const float cur = proc[i];
+            const bool flag = (i >= 1) && fabs((double)cur - (double)prev) > 0.6;
+            mymask |= (uint64_t)flag << (i - first);
+            prev = cur;
+        }
     }
     const int cnt = __popcll(mymask);
     int incl = cnt;
@@ -672,12 +676,12 @@ __device__ __forceinline__ void policy_disparity(const DeviceParams& P, float* _
     const int excl = incl - cnt;
     const int total = __builtin_amdgcn_readlane(incl, FTGP_WAVE - 1);
     for (int c0 = 0; c0 < total; c0 += FTGP_WAVE) {
-        {   // indices of disparities c0 .. c0 + 63, in order: lane p owns the set bits of pass p
+        {   // indices of disparities c0 .. c0 + 63, in order: lane l owns the set bits of its samples
             uint64_t mk = mymask; int rank = excl;
             while (mk) {
                 const int bit = __builtin_ctzll(mk);
                 mk &= mk - 1;
-                if (rank >= c0 && rank < c0 + FTGP_WAVE) list[rank - c0] = lane * FTGP_WAVE + bit;
+                if (rank >= c0 && rank < c0 + FTGP_WAVE) list[rank - c0] = first + bit;
                 ++rank;
             }
         }
@@ -710,15 +714,18 @@ __device__ __forceinline__ void policy_disparity(const DeviceParams& P, float* _
         }
     }
     wave_lds_sync();
-    // argmax, first maximum (nidc.py:127)
+    // argmax, first maximum (nidc.py:127): every lane scans its own samples in index order, lanes are merged with "the lower
+    // index wins ties"; sample 0 is the running maximum to begin with, whatever it is (a NaN there stays, like numpy's loop)
     float bv = -INFINITY; int bi = 0x7fffffff;
-    for (int i = lane; i < m; i += FTGP_WAVE) { const float x = proc[i]; if (bi == 0x7fffffff || x > bv) { bv = x; bi = i; } }
+    if (lane == 0) { bv = proc[0]; bi = 0; }
+    for (int i = first + (lane == 0 ? 1 : 0); i < end; ++i) { const float x = proc[i]; if (x > bv) { bv = x; bi = i; } }
     #pragma unroll
     for (int mm = 32; mm >= 1; mm >>= 1) {
         const float ov = __shfl_xor(bv, mm, FTGP_WAVE);
         const int oi = __shfl_xor(bi, mm, FTGP_WAVE);
         if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
     }
+    bi = __builtin_amdgcn_readfirstlane(bi);                        // lane 0's merge order is the sequential one
     double ang = ((double)bi - ((double)m / 2)) * rpp;              // nidc.py:112
     const double lim = 90.0 * (M_PI / 180.0);
     if (ang < -lim) ang = -lim;
