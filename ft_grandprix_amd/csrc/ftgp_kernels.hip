@@ -208,11 +208,14 @@ __device__ __forceinline__ void lidar_pool(const DeviceParams& P, const Lds& L, 
                         if (rc < INFINITY && (r < 0.0f || rc < r)) r = rc;
                     }
             }
-            *(global_f32)((global_u8w)ranges + ((uint32_t)(__mul24(c, stride) + j) << 2)) = r;      // SGPR base + 32-bit lane offset
-            if (scan_lds) {          // the on-device driver only reads ranges[0] and ranges[eighth : n - eighth]
+            // the on-device drivers read ranges[0] and ranges[eighth : n - eighth]: that window is kept in LDS and goes to HBM as whole
+            // lines once the sweep is over (window_flush); everything else is stored ray by ray (4-byte stores that merge in L2)
+            const int jw = j - eighth;
+            const bool in_window = scan_lds && (unsigned)jw < (unsigned)(R - 2 * eighth);
+            if (!in_window) *(global_f32)((global_u8w)ranges + ((uint32_t)(__mul24(c, stride) + j) << 2)) = r;      // SGPR base + 32-bit lane offset
+            if (scan_lds) {
                 float* row = scan_rows + __mul24(c, win_floats);
-                const int jw = j - eighth;
-                if ((unsigned)jw < (unsigned)(R - 2 * eighth)) row[1 + jw] = r;
+                if (in_window) row[1 + jw] = r;
                 if (j == 0) row[0] = r;
             }
             cj = -1;
@@ -266,6 +269,16 @@ __device__ __forceinline__ void lidar_pool(const DeviceParams& P, const Lds& L, 
             if (__popcll(done_mask) >= want) { done = (done_mask >> lane) & 1ull; break; }
         }
     }
+}
+
+// The scan window of car slot c (LDS row: [0] = ranges[0], [1 ...] = ranges[eighth : n - eighth]) to its row in HBM, by one wave:
+// consecutive lanes store consecutive floats, i.e. whole 128-byte lines except at the two ends of the window.
+__device__ __forceinline__ void window_flush(const DeviceParams& P, const float* __restrict__ row, int ci)
+{
+    typedef __attribute__((address_space(1))) float* global_f32;
+    const int eighth = sgpr(P.eighth), n = sgpr(P.n_rays) - 2 * eighth;
+    const global_f32 dst = (global_f32)uniform_ptr(P.ranges) + (size_t)ci * sgpr(P.ranges_stride) + eighth;
+    for (int i = lane_here(); i < n; i += FTGP_WAVE) dst[i] = row[1 + i];
 }
 
 // device arithmetic the kernels rely on, checked over every binary32 bit pattern: rcp_abs(x) == |1 / x| (IEEE division)
@@ -859,6 +872,7 @@ __global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(cons
         if (wave < ncars_here) __builtin_amdgcn_s_setprio(3);
 #endif
         for (int c = wave; c < ncars_here; c += nwaves) {
+            if (need_scan && it > 0) window_flush(P, scan_prev + c * win_floats, ci0 + c);     // the previous sweep's window, before the driver edits it
             if (policy != FTGP_POLICY_HOST) policy_apply(P, policy, scan_prev + c * win_floats, L.cars + c, ci0 + c, L.steps[c], L.list + wave * FTGP_WAVE, L.cover);
             wave_lds_sync();
             int n = 0;
@@ -893,6 +907,8 @@ __global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(cons
     const Lds L = lds_view(off, lds);
     for (int c = wave; c < ncars_here; c += nwaves) {
         const int ci = ci0 + c;
+        if (need_scan && n_steps > 0)          // the last sweep's window
+            window_flush(P, L.scan + (((n_steps - 1) & 1) * cpb + c) * P.win_floats, ci);
         if (lane < (int)(sizeof(CarCore) / 4))
             reinterpret_cast<uint32_t*>(static_cast<CarCore*>(&P.cars[ci]))[lane] = reinterpret_cast<const uint32_t*>(L.cars + c)[lane];
         if (lane == 0 && ci % P.cars_per_env == 0) P.steps[ci / P.cars_per_env] = L.steps[c];
