@@ -371,7 +371,7 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
         const float tiny = 1.401298464e-45f;
         P.cover_kmax = std::max(1, std::max(cover_count_host(0.24, rpp, (double)tiny), cover_count_host(0.12, rpp, (double)tiny)));
     }
-    P.win_floats = (1 + (cfg->n_rays - 2 * P.eighth) + 3) & ~3;
+    P.win_floats = ((P.eighth & 3) + (cfg->n_rays - 2 * P.eighth) + 1 + 3) & ~3;       // window at float (eighth % 4), ranges[0] in the last float
     P.snap_eps = ftgp_snap_eps(t.width, t.height);
     P.ray_magic = (uint32_t)((0x100000000ull + (uint64_t)cfg->n_rays - 1) / (uint64_t)cfg->n_rays);
 

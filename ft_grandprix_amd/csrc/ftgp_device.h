@@ -53,7 +53,7 @@ struct DeviceParams {
     uint32_t plane256;            // bytes per (padded) sector plane of the box field / 256
     int32_t contact_reach;        // chessboard reach (pixels) of the wall-contact window; `nearbits` is the wall set dilated by it
     // step-kernel launch shape and LDS layout (byte offsets, all 16-B aligned)
-    int32_t cars_per_block, waves_per_block, eighth, win_floats;   // win_floats: floats per LDS scan row = 1 + (n_rays - 2*eighth), padded to 4
+    int32_t cars_per_block, waves_per_block, eighth, win_floats;   // win_floats: floats per LDS scan row: (eighth % 4) + (n_rays - 2*eighth) + 1, padded to 4
     int32_t off_params, off_veh, off_path, off_ray, off_cars, off_frame, off_steps, off_scan, off_list, off_pool, off_k1, off_cover, lds_bytes, cover_kmax;
     int32_t bubble_wrap, pad_b;   // custom.py:1041-1055: the four wheel softeners collide with the walls
     const uint16_t* field;        // [FTGP_SECTORS][height + 2][width + 2] box entries (ftgp_march.h), HBM/L2

@@ -36,7 +36,7 @@ struct Lds {
     CarCore* cars;
     LidarFrame* frame;        // [2][cars_per_block], double-buffered by step parity
     int64_t* steps;
-    float* scan;              // [2][cars_per_block][win_floats]: ranges[0] | ranges[eighth : n - eighth], double-buffered by step parity
+    float* scan;              // [2][cars_per_block][win_floats] scan windows (layout: scan_window_* below), double-buffered by step parity
     int* list;                // [waves_per_block][64] driver scratch
     int* pool;                // [2] next ray of the sweep, [2] drivers finished -- both double-buffered by step parity
     Force* terms;             // [cars_per_block][FTGP_FORCE_TERMS] K1 staging: force terms in the order they are summed
@@ -44,6 +44,11 @@ struct Lds {
     Dyn* next;                // [cars_per_block] K1 staging: new dynamic state before the commit
     const float* cover;       // [cover_kmax + 1] cover-count thresholds of the launch's driver (see cover_count)
 };
+
+// LDS scan window of one car: the samples the on-device drivers read.  Sample ranges[eighth + i] sits at float index
+// (eighth % 4) + i, so that LDS and HBM addresses of a sample agree modulo 16 bytes (whole float4 groups move with one
+// ds_read_b128 + one global_store_dwordx4); ranges[0] (fast.py:135) sits in the last float of the row.
+__device__ __forceinline__ int scan_window_first(int eighth) { return eighth & 3; }
 
 // A wave-uniform value the optimiser cannot see through.  The step loop rebuilds its LDS pointers from such offsets every
 // step, so loads of constants (vehicle parameters, centre-line, ...) are never hoisted out of the loop -- hoisted, they
@@ -215,8 +220,8 @@ __device__ __forceinline__ void lidar_pool(const DeviceParams& P, const Lds& L, 
             if (!in_window) *(global_f32)((global_u8w)ranges + ((uint32_t)(__mul24(c, stride) + j) << 2)) = r;      // SGPR base + 32-bit lane offset
             if (scan_lds) {
                 float* row = scan_rows + __mul24(c, win_floats);
-                if (in_window) row[1 + jw] = r;
-                if (j == 0) row[0] = r;
+                if (in_window) row[(eighth & 3) + jw] = r;
+                if (j == 0) row[win_floats - 1] = r;
             }
             cj = -1;
         }
@@ -271,14 +276,24 @@ __device__ __forceinline__ void lidar_pool(const DeviceParams& P, const Lds& L, 
     }
 }
 
-// The scan window of car slot c (LDS row: [0] = ranges[0], [1 ...] = ranges[eighth : n - eighth]) to its row in HBM, by one wave:
-// consecutive lanes store consecutive floats, i.e. whole 128-byte lines except at the two ends of the window.
+// The scan window of a car (LDS row, see scan_window_first) to its row in HBM, by one wave: whole float4 groups -- 16 bytes per
+// lane, whole 128-byte lines per 8 lanes -- and single floats only at the two ragged ends of the window.
 __device__ __forceinline__ void window_flush(const DeviceParams& P, const float* __restrict__ row, int ci)
 {
     typedef __attribute__((address_space(1))) float* global_f32;
-    const int eighth = sgpr(P.eighth), n = sgpr(P.n_rays) - 2 * eighth;
-    const global_f32 dst = (global_f32)uniform_ptr(P.ranges) + (size_t)ci * sgpr(P.ranges_stride) + eighth;
-    for (int i = lane_here(); i < n; i += FTGP_WAVE) dst[i] = row[1 + i];
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(1))) f32x4* global_f32x4;
+    const int eighth = sgpr(P.eighth), n = sgpr(P.n_rays) - 2 * eighth, w0 = eighth & 3;
+    // LDS float index q <-> HBM float index (eighth - w0) + q of the car's row; the window is q in [w0, w0 + n)
+    const global_f32 dst = (global_f32)uniform_ptr(P.ranges) + (size_t)ci * sgpr(P.ranges_stride) + (eighth - w0);
+    const int lane = lane_here();
+    const int g0 = w0 ? 1 : 0, g1 = (w0 + n) >> 2;                   // float4 groups [g0, g1) lie entirely inside the window
+    for (int g = g0 + lane; g < g1; g += FTGP_WAVE) ((global_f32x4)dst)[g] = reinterpret_cast<const f32x4*>(row)[g];
+    if (lane < 4) {                                                  // the ragged ends: floats [w0, 4) of group 0 and [4 * g1, w0 + n)
+        if (w0 && lane >= w0 && lane < w0 + n) dst[lane] = row[lane];
+        const int q = 4 * g1 + lane;
+        if (q < w0 + n && q >= 4 * g0) dst[q] = row[q];
+    }
 }
 
 // device arithmetic the kernels rely on, checked over every binary32 bit pattern: rcp_abs(x) == |1 / x| (IEEE division)
@@ -665,8 +680,8 @@ __device__ __forceinline__ void policy_disparity(const DeviceParams& P, float* _
     const double rpp = (2 * M_PI) / (double)n;                      // nidc.py:121
     const int eighth = P.eighth;                                    // int(n / 8), nidc.py:18
     const int m = n - 2 * eighth;
-    float* __restrict__ proc = scan + 1;
-    const float range0 = scan[0];                                   // ranges[0], fast.py:135
+    float* __restrict__ proc = scan + scan_window_first(eighth);
+    const float range0 = scan[P.win_floats - 1];                    // ranges[0], fast.py:135
     const int kmax = P.cover_kmax;                                  // thr = the cover-count thresholds of this driver (width = (car_width / 2) * (1 + 300 / 100), nidc.py:93)
     // disparity flags (nidc.py:26-40, on the unmodified scan): lane l owns the contiguous samples [l * chunk, (l + 1) * chunk) and
     // keeps its flags as bits of mymask; launch_steps() guarantees m <= 64 * 64, i.e. chunk <= 64
@@ -836,8 +851,8 @@ __global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(cons
         if (need_scan) {     // the scan of the previous launch is what the first driver call sees: buffer 1 = parity of step -1
             const float* my_ranges = P.ranges + (size_t)ci * P.ranges_stride;
             float* row = L.scan + (cpb + c) * win_floats;
-            if (lane == 0) row[0] = my_ranges[0];
-            for (int j = eighth + lane; j < R - eighth; j += FTGP_WAVE) row[1 + j - eighth] = my_ranges[j];
+            if (lane == 0) row[win_floats - 1] = my_ranges[0];
+            for (int j = eighth + lane; j < R - eighth; j += FTGP_WAVE) row[scan_window_first(eighth) + j - eighth] = my_ranges[j];
         }
         wave_lds_sync();
         if (lane == 0) frame_write(P, L.veh->v, L.cars + c, L.frame + c);
@@ -931,8 +946,8 @@ __global__ void __launch_bounds__(256) ftgp_policy_kernel(DeviceParams P, int po
     int* list = reinterpret_cast<int*>(lds + 4 * sizeof(CarCore)) + wave * FTGP_WAVE;
     float* scan = reinterpret_cast<float*>(lds + 4 * sizeof(CarCore) + 4 * FTGP_WAVE * sizeof(int)) + wave * win_floats;
     const float* my_ranges = P.ranges + (size_t)ci * P.ranges_stride;
-    if (lane == 0) scan[0] = my_ranges[0];
-    for (int j = P.eighth + lane; j < P.n_rays - P.eighth; j += FTGP_WAVE) scan[1 + j - P.eighth] = my_ranges[j];
+    if (lane == 0) scan[win_floats - 1] = my_ranges[0];
+    for (int j = P.eighth + lane; j < P.n_rays - P.eighth; j += FTGP_WAVE) scan[scan_window_first(P.eighth) + j - P.eighth] = my_ranges[j];
     if (lane < (int)(sizeof(CarCore) / 4))
         reinterpret_cast<uint32_t*>(st)[lane] = reinterpret_cast<const uint32_t*>(static_cast<const CarCore*>(&P.cars[ci]))[lane];
     wave_lds_sync();

@@ -88,6 +88,19 @@ def test_closed_loop_1000_steps(product, oracle, policy):
         assert g.steps()[0] == 1000
 
 
+@pytest.mark.parametrize("R", [8, 37, 2000, 4100])
+def test_odd_ray_counts_closed_loop(product, oracle, R):
+    """Ray counts away from 1080: a window that is not a multiple of anything (37), the smallest the drivers accept (8),
+    and scans long enough for more than 32 samples per lane in the driver passes (4100: 49 per lane) -- the workgroup
+    shape, the LDS window layout and its float4 flush all depend on R."""
+    t = load_track("circle")
+    g, o = both(product, oracle, t, n_envs=20, n_rays=R, spawn_mode=1, seed=9, lap_target=2)
+    with g, o:
+        for policy, steps in (("fast", 150), ("nidc", 150)):
+            g.rollout(policy, steps); o.rollout(policy, steps)
+            assert_same_state(g, o)
+
+
 def test_small_config_36_rays_template_driver(product, oracle):
     """Config 1: 1 env, small-circle, 36 rays, drivers.template (returns (0, 0)) through the host driver path."""
     from ft_grandprix_amd.sim import Simulator
