@@ -53,7 +53,8 @@ class FtgpVehicle(C.Structure):
                 ("lidar_x", C.c_double), ("lidar_y", C.c_double), ("lidar_ring_radius", C.c_double),
                 ("body_z", C.c_double),
                 ("box_xmin", C.c_double), ("box_xmax", C.c_double), ("box_ymin", C.c_double), ("box_ymax", C.c_double),
-                ("softener_radius", C.c_double)]
+                ("softener_radius", C.c_double), ("motor_forward_limit", C.c_double), ("motor_turn_limit", C.c_double),
+                ("kind", C.c_int32), ("reserved1", C.c_int32)]
 
 
 class FtgpConfig(C.Structure):
@@ -66,7 +67,7 @@ class FtgpConfig(C.Structure):
 
 # every symbol include/ftgp.h declares (checked by tests/test_capi.py)
 API_SYMBOLS = (
-    "default_vehicle", "last_error", "device_count", "create", "destroy", "reset", "set_ctrl", "step",
+    "default_vehicle", "tricycle_vehicle", "last_error", "device_count", "create", "destroy", "reset", "set_ctrl", "step",
     "rollout", "get_lidar", "get_snapshot", "get_pose", "get_progress", "get_lap_times", "get_ctrl",
     "get_steps", "set_pose", "policy_eval", "eval_progress", "metrics_local", "comm_unique_id", "comm_init", "metrics_allgather",
     "last_kernel_ms", "kernel_name", "fakelidar", "selftest",
@@ -105,6 +106,7 @@ class CLib:
         vp, i32, dp = C.c_void_p, C.c_int, C.c_void_p
         sigs = {
             "default_vehicle": (None, [C.POINTER(FtgpVehicle)]),
+            "tricycle_vehicle": (None, [C.POINTER(FtgpVehicle)]),
             "last_error": (C.c_char_p, []),
             "create": (i32, [C.POINTER(FtgpConfig), C.POINTER(vp)]),
             "destroy": (i32, [vp]),
@@ -150,6 +152,12 @@ class CLib:
     def default_vehicle(self) -> FtgpVehicle:
         v = FtgpVehicle()
         self.fn("default_vehicle")(C.byref(v))
+        return v
+
+    def tricycle_vehicle(self) -> FtgpVehicle:
+        """The legacy differential-drive car of template/car.em.xml (pair it with dt = 0.0075)."""
+        v = FtgpVehicle()
+        self.fn("tricycle_vehicle")(C.byref(v))
         return v
 
 

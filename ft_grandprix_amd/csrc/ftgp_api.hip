@@ -272,6 +272,35 @@ void ftgp_default_vehicle(FtgpVehicle* v)
     v->softener_radius = 0.65 * 0.0488;                                        // mushr_wheel.stl radius x (mushr_scale * 1.3) (:39,65-67)
 }
 
+
+void ftgp_tricycle_vehicle(FtgpVehicle* v)
+{
+    memset(v, 0, sizeof *v);
+    v->kind = FTGP_VEHICLE_TRICYCLE;
+    // masses: chassis mesh = convex hull of its 9 vertices at scale (0.01, 0.006, 0.0015), default density 1000 (car.em.xml:52,66): 0.4158
+    // + LiDAR puck (density 2000, r 0.03, half-height 0.015; :78) 0.1696 + three wheels of 0.5 / 3 (:86,96,108,119)
+    v->mass = 1.085446;
+    v->izz = 0.005886;               // of those parts about the body origin
+    v->wheel_x[0] = -0.07; v->wheel_y[0] = 0.06;      // left driven wheel (:97)
+    v->wheel_x[1] = -0.07; v->wheel_y[1] = -0.06;     // right driven wheel (:110)
+    v->wheel_x[2] = 0.08;  v->wheel_y[2] = 0.0;       // front caster: condim 1, frictionless (:96) -- carries load, transmits no force
+    v->wheel_radius = 0.03;                           // cylinder size 0.03 0.01 (:24)
+    v->wheel_inertia = 0.5 * (0.5 / 3.0) * 0.03 * 0.03;   // solid cylinder about its axle
+    v->wheel_damping = 0.03;                          // default joint damping (:22)
+    v->motor_forward_limit = 4.0; v->motor_turn_limit = 1.0;   // ctrlrange (:138-139)
+    v->friction = 1.0; v->gravity = 9.81;             // MuJoCo default friction of wheel and plane
+    v->tire_damping = (v->mass * (0.08 / 0.15) / 2.0) * (2.0 / (0.95 * 0.02));   // the load share of one driven wheel; solimp dmax 0.95 (:24), solref 0.02
+    v->contact_x[0] = 0.045; v->contact_x[1] = 0.0; v->contact_x[2] = -0.045;    // chassis footprint 0.2 x 0.12 as three circles
+    v->contact_radius = 0.06;
+    v->contact_stiffness = v->mass / (0.95 * 0.95 * 0.02 * 0.02);
+    v->contact_damping = v->mass * (2.0 / (0.95 * 0.02));
+    v->lidar_x = -0.0525; v->lidar_y = 0.0; v->lidar_ring_radius = 0.03;         // (:72-76)
+    v->body_z = 0.04;
+    v->box_xmin = -0.10; v->box_xmax = 0.10; v->box_ymin = -0.06; v->box_ymax = 0.06;   // mesh bbox
+    v->softener_radius = 0.035;                       // softener spheres (:93,104,116)
+    v->steer_limit = 1.0; v->steer_inertia = 1.0;     // unused (no steering joint)
+}
+
 const char* ftgp_last_error(void) { return g_err; }
 
 int ftgp_device_count(void)
@@ -316,7 +345,8 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
     if (cfg->env_base < 0) return fail(FTGP_ERR_ARG, "env_base < 0%s");
     if (!(cfg->dt > 0.0) || !(t.px_size_x > 0.0) || !(t.px_size_y > 0.0)) return fail(FTGP_ERR_ARG, "bad dt / pixel size%s");
     const FtgpVehicle& v = cfg->vehicle;
-    if (!(v.contact_radius > 0.0) || !(v.mass > 0.0) || !(v.izz > 0.0)) return fail(FTGP_ERR_ARG, "bad vehicle%s");
+    if (!(v.contact_radius > 0.0) || !(v.mass > 0.0) || !(v.izz > 0.0) || (v.kind != FTGP_VEHICLE_MUSHR && v.kind != FTGP_VEHICLE_TRICYCLE))
+        return fail(FTGP_ERR_ARG, "bad vehicle%s");
     if (cfg->bubble_wrap && !(v.softener_radius > 0.0)) return fail(FTGP_ERR_ARG, "bubble_wrap needs vehicle.softener_radius > 0%s");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
@@ -355,10 +385,16 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
     P.inv_px_x_f = (float)P.inv_px_x; P.inv_px_y_f = (float)P.inv_px_y;
     P.veh = cfg->vehicle;
     {   // static wheel loads from the wheelbase split
-        const double a_f = 0.5 * (v.wheel_x[0] + v.wheel_x[1]), a_r = -0.5 * (v.wheel_x[2] + v.wheel_x[3]);
         const double wtot = v.mass * v.gravity;
-        P.wheel_load[0] = P.wheel_load[1] = 0.5 * (wtot * (a_r / (a_f + a_r)));
-        P.wheel_load[2] = P.wheel_load[3] = 0.5 * (wtot * (a_f / (a_f + a_r)));
+        if (v.kind == FTGP_VEHICLE_TRICYCLE) {       // two driven wheels behind the origin, the caster (wheel 2) in front
+            const double a_f = v.wheel_x[2], a_r = -0.5 * (v.wheel_x[0] + v.wheel_x[1]);
+            P.wheel_load[0] = P.wheel_load[1] = 0.5 * (wtot * (a_f / (a_f + a_r)));
+            P.wheel_load[2] = wtot * (a_r / (a_f + a_r)); P.wheel_load[3] = 0.0;
+        } else {
+            const double a_f = 0.5 * (v.wheel_x[0] + v.wheel_x[1]), a_r = -0.5 * (v.wheel_x[2] + v.wheel_x[3]);
+            P.wheel_load[0] = P.wheel_load[1] = 0.5 * (wtot * (a_r / (a_f + a_r)));
+            P.wheel_load[2] = P.wheel_load[3] = 0.5 * (wtot * (a_f / (a_f + a_r)));
+        }
     }
     e->multi = cfg->cars_per_env > 1;
     {   // chessboard reach of the largest wall-contact window

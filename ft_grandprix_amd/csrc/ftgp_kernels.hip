@@ -544,7 +544,8 @@ __device__ __forceinline__ void dynamics_lanes(const DeviceParams& P, const Lds&
         const double q = st->qs;
         const double c1 = (r == 0) ? 0.375 : -0.375, c3 = (r == 0) ? -0.0722656 : 0.0722656;
         const double steer = q * (1.0 + q * (c1 + q * (0.140625 + q * c3)));
-        const double ang = (r < 2) ? steer : 0.0;                       // the rear wheels do not steer: the polynomials give exactly (1, 0) at 0
+        const bool tri = v.kind == FTGP_VEHICLE_TRICYCLE;               // legacy differential-drive car (car.em.xml): no steering, two driven wheels
+        const double ang = (!tri && r < 2) ? steer : 0.0;               // wheels that do not steer: the polynomials give exactly (1, 0) at 0
         const double cwi = spec_cos(ang), swi = spec_sin(ang);
         // velocity servo on the tendon = mean wheel spin, mushr.em.xml:180,191-196
         const double wbar = 0.25 * (((st->w[0] + st->w[1]) + st->w[2]) + st->w[3]);
@@ -552,6 +553,15 @@ __device__ __forceinline__ void dynamics_lanes(const DeviceParams& P, const Lds&
         if (fa > v.throttle_force_limit) fa = v.throttle_force_limit;
         if (fa < -v.throttle_force_limit) fa = -v.throttle_force_limit;
         const double ta = (v.throttle_gear * 0.25) * fa;
+        // tricycle: two torque motors on the tendons 0.5 (l + r) and 0.5 (r - l), controls clamped to their ctrlrange (car.em.xml:126-139)
+        double uf = st->u_speed, ut = st->u_steer;
+        if (uf > v.motor_forward_limit) uf = v.motor_forward_limit;
+        if (uf < -v.motor_forward_limit) uf = -v.motor_forward_limit;
+        if (ut > v.motor_turn_limit) ut = v.motor_turn_limit;
+        if (ut < -v.motor_turn_limit) ut = -v.motor_turn_limit;
+        const double tl = 0.5 * uf - 0.5 * ut, tr = 0.5 * uf + 0.5 * ut;
+        const double torque = tri ? (r == 0 ? tl : tr) : ta;
+        const bool rolling = !(tri && r >= 2);                          // the caster is frictionless and there is no fourth wheel
         const double wi = st->w[r];
         const double wx_ = v.wheel_x[r], wy_ = v.wheel_y[r];
         const double rxw = ch * wx_ - sh * wy_;
@@ -566,8 +576,9 @@ __device__ __forceinline__ void dynamics_lanes(const DeviceParams& P, const Lds&
         if (m2 > lim * lim) { const double sc = lim / sqrt(m2); flong = flong * sc; flat = flat * sc; }
         Force t;
         t.fx = flong * fdx - flat * fdy; t.fy = flong * fdy + flat * fdx; t.tz = rxw * t.fy - ryw * t.fx;
-        const double wn = (v.wheel_inertia * wi + dt * (ta - v.wheel_radius * flong)) / (v.wheel_inertia + dt * v.wheel_damping);
-        if (on) { terms[r] = t; L.wnew[(on ? c : 0) * 4 + r] = wn; }
+        const double wn = (v.wheel_inertia * wi + dt * (torque - v.wheel_radius * flong)) / (v.wheel_inertia + dt * v.wheel_damping);
+        if (!rolling) { t.fx = 0.0; t.fy = 0.0; t.tz = 0.0; }
+        if (on) { terms[r] = t; L.wnew[(on ? c : 0) * 4 + r] = rolling ? wn : wi; }
     }
     FTGP_FORGET_REGISTERS();
     {   // ---- wall-contact circle r and wheel softener r (a shadowed car collides with nothing, custom.py:1452-1457)
@@ -599,6 +610,7 @@ __device__ __forceinline__ void dynamics_lanes(const DeviceParams& P, const Lds&
         o.qs = st->qs + dt * o.qsd;
         if (o.qs > v.steer_limit) { o.qs = v.steer_limit; if (o.qsd > 0.0) o.qsd = 0.0; }
         if (o.qs < -v.steer_limit) { o.qs = -v.steer_limit; if (o.qsd < 0.0) o.qsd = 0.0; }
+        if (v.kind == FTGP_VEHICLE_TRICYCLE) { o.qs = st->qs; o.qsd = st->qsd; }       // no steering joint
         // semi-implicit Euler: positions with the new velocities
         const double h = (0.5 * dt) * o.wz;
         const double chh = spec_cos(h), shh = spec_sin(h);

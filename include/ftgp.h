@@ -40,6 +40,9 @@ extern "C" {
 #define FTGP_POLICY_FAST      3  /* ft_grandprix/fast.py:118-139 : same + straight-line boost */
 #define FTGP_POLICY_RANDOM    4  /* counter-based RNG keyed (seed, car, step): speed~U(0,3), steer~U(-1,1) */
 
+#define FTGP_VEHICLE_MUSHR     0
+#define FTGP_VEHICLE_TRICYCLE  1
+
 #define FTGP_PATH_POINTS   100   /* ft_grandprix/curve.py:8 */
 #define FTGP_MAX_LAP_TIMES  32   /* lap times kept per car (the oldest are kept; VehicleState.times is unbounded, lap_target defaults to 10, custom.py:124,961) */
 
@@ -90,6 +93,12 @@ typedef struct FtgpVehicle {
     double box_xmin, box_xmax, box_ymin, box_ymax; /* chassis bbox, body frame, seen by other cars' rays */
     double softener_radius;         /* bubble_wrap: wall-contact circles at the four wheel positions; 0.65 * 0.0488 = radius of
                                        meshes/mushr_wheel.stl at the scale of mushr.em.xml:39 (softener geoms, mushr.em.xml:65-67) */
+    double motor_forward_limit, motor_turn_limit; /* FTGP_VEHICLE_TRICYCLE: ctrlrange of the two torque motors (car.em.xml:138-139) */
+    int32_t kind;                   /* FTGP_VEHICLE_MUSHR: Ackermann car with a velocity servo and a steering servo (mushr.em.xml);
+                                       FTGP_VEHICLE_TRICYCLE: the legacy differential-drive car of template/car.em.xml (option tricycle_mode,
+                                       custom.py:1154-1170): wheels 0 / 1 = left / right driven wheels, wheel 2 = frictionless front caster,
+                                       ctrl = (forward torque, turn torque) on the tendons 0.5 (l + r) and 0.5 (r - l) (car.em.xml:126-139) */
+    int32_t reserved1;
 } FtgpVehicle;
 
 typedef struct FtgpConfig {
@@ -117,6 +126,9 @@ typedef struct FtgpEnv FtgpEnv;
 
 /* Fill *v with the MuSHR constants of template/mushr.em.xml. */
 void ftgp_default_vehicle(FtgpVehicle *v);
+
+/* Fill *v with the constants of the legacy tricycle of template/car.em.xml (use FtgpConfig.dt = 0.0075, car.em.xml:11). */
+void ftgp_tricycle_vehicle(FtgpVehicle *v);
 
 /* Text of the last error raised on the calling thread. */
 const char *ftgp_last_error(void);

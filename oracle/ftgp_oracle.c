@@ -109,6 +109,35 @@ void oracle_default_vehicle(FtgpVehicle *v)
     v->softener_radius = 0.65 * 0.0488;   /* mushr_wheel.stl radius at the scale of mushr.em.xml:39 */
 }
 
+
+void oracle_tricycle_vehicle(FtgpVehicle* v)
+{
+    memset(v, 0, sizeof *v);
+    v->kind = FTGP_VEHICLE_TRICYCLE;
+    // masses: chassis mesh = convex hull of its 9 vertices at scale (0.01, 0.006, 0.0015), default density 1000 (car.em.xml:52,66): 0.4158
+    // + LiDAR puck (density 2000, r 0.03, half-height 0.015; :78) 0.1696 + three wheels of 0.5 / 3 (:86,96,108,119)
+    v->mass = 1.085446;
+    v->izz = 0.005886;               // of those parts about the body origin
+    v->wheel_x[0] = -0.07; v->wheel_y[0] = 0.06;      // left driven wheel (:97)
+    v->wheel_x[1] = -0.07; v->wheel_y[1] = -0.06;     // right driven wheel (:110)
+    v->wheel_x[2] = 0.08;  v->wheel_y[2] = 0.0;       // front caster: condim 1, frictionless (:96) -- carries load, transmits no force
+    v->wheel_radius = 0.03;                           // cylinder size 0.03 0.01 (:24)
+    v->wheel_inertia = 0.5 * (0.5 / 3.0) * 0.03 * 0.03;   // solid cylinder about its axle
+    v->wheel_damping = 0.03;                          // default joint damping (:22)
+    v->motor_forward_limit = 4.0; v->motor_turn_limit = 1.0;   // ctrlrange (:138-139)
+    v->friction = 1.0; v->gravity = 9.81;             // MuJoCo default friction of wheel and plane
+    v->tire_damping = (v->mass * (0.08 / 0.15) / 2.0) * (2.0 / (0.95 * 0.02));   // the load share of one driven wheel; solimp dmax 0.95 (:24), solref 0.02
+    v->contact_x[0] = 0.045; v->contact_x[1] = 0.0; v->contact_x[2] = -0.045;    // chassis footprint 0.2 x 0.12 as three circles
+    v->contact_radius = 0.06;
+    v->contact_stiffness = v->mass / (0.95 * 0.95 * 0.02 * 0.02);
+    v->contact_damping = v->mass * (2.0 / (0.95 * 0.02));
+    v->lidar_x = -0.0525; v->lidar_y = 0.0; v->lidar_ring_radius = 0.03;         // (:72-76)
+    v->body_z = 0.04;
+    v->box_xmin = -0.10; v->box_xmax = 0.10; v->box_ymin = -0.06; v->box_ymax = 0.06;   // mesh bbox
+    v->softener_radius = 0.035;                       // softener spheres (:93,104,116)
+    v->steer_limit = 1.0; v->steer_inertia = 1.0;     // unused (no steering joint)
+}
+
 /* ------------------------------------------------------------------ small math (specified polynomials) */
 /* sin/cos by Taylor series in Horner form on x*x; accurate to < 1e-15 for |x| <= 1.7 (the only range used). */
 static double spec_sin(double x)
@@ -562,12 +591,23 @@ static void integrate_car(const OracleEnv *e, int ci, Car *out)
     if (fa > v->throttle_force_limit) fa = v->throttle_force_limit;
     if (fa < -v->throttle_force_limit) fa = -v->throttle_force_limit;
     const double ta = (v->throttle_gear * 0.25) * fa;
+    /* legacy tricycle (car.em.xml:126-139): two torque motors on the tendons 0.5 (l + r) and 0.5 (r - l), ctrl clamped to ctrlrange */
+    const int tri = v->kind == FTGP_VEHICLE_TRICYCLE;
+    double uf = a->u_speed, ut = a->u_steer;
+    if (uf > v->motor_forward_limit) uf = v->motor_forward_limit;
+    if (uf < -v->motor_forward_limit) uf = -v->motor_forward_limit;
+    if (ut > v->motor_turn_limit) ut = v->motor_turn_limit;
+    if (ut < -v->motor_turn_limit) ut = -v->motor_turn_limit;
+    const double tl = 0.5 * uf - 0.5 * ut, tr = 0.5 * uf + 0.5 * ut;
     Force f = { 0.0, 0.0, 0.0 };
     for (int i = 0; i < 4; ++i) {
+        if (tri && i >= 2) continue;                  /* front caster: frictionless; there is no fourth wheel */
+        const double torque = tri ? (i == 0 ? tl : tr) : ta;
+        const double cwi = tri ? 1.0 : cw[i], swi = tri ? 0.0 : sw[i];
         double rxw = ch * v->wheel_x[i] - sh * v->wheel_y[i];
         double ryw = sh * v->wheel_x[i] + ch * v->wheel_y[i];
         double vpx = a->vx - a->wz * ryw, vpy = a->vy + a->wz * rxw;
-        double fdx = ch * cw[i] - sh * sw[i], fdy = sh * cw[i] + ch * sw[i];   /* wheel heading, world */
+        double fdx = ch * cwi - sh * swi, fdy = sh * cwi + ch * swi;             /* wheel heading, world */
         double vlong = (vpx * fdx + vpy * fdy) - v->wheel_radius * a->w[i];
         double vlat = vpy * fdx - vpx * fdy;                                    /* along (-fdy, fdx) */
         double flong = -(v->tire_damping * vlong), flat = -(v->tire_damping * vlat);
@@ -576,18 +616,20 @@ static void integrate_car(const OracleEnv *e, int ci, Car *out)
         if (m2 > lim * lim) { double sc = lim / sqrt(m2); flong = flong * sc; flat = flat * sc; }
         double fx = flong * fdx - flat * fdy, fy = flong * fdy + flat * fdx;
         f.fx += fx; f.fy += fy; f.tz += rxw * fy - ryw * fx;
-        out->w[i] = (v->wheel_inertia * a->w[i] + dt * (ta - v->wheel_radius * flong)) / (v->wheel_inertia + dt * v->wheel_damping);
+        out->w[i] = (v->wheel_inertia * a->w[i] + dt * (torque - v->wheel_radius * flong)) / (v->wheel_inertia + dt * v->wheel_damping);
     }
     if (!a->finished) wall_contact(e, a, ch, sh, &f);
     if (c->cars_per_env > 1) car_contact(e, ci, ch, sh, &f);
     out->vx = a->vx + dt * (f.fx / v->mass);
     out->vy = a->vy + dt * (f.fy / v->mass);
     out->wz = a->wz + dt * (f.tz / v->izz);
-    /* steering servo, implicit damping */
-    out->qsd = (v->steer_inertia * a->qsd + dt * (v->steer_kp * (a->u_steer - a->qs))) / (v->steer_inertia + dt * v->steer_damping);
-    out->qs = a->qs + dt * out->qsd;
-    if (out->qs > v->steer_limit) { out->qs = v->steer_limit; if (out->qsd > 0.0) out->qsd = 0.0; }
-    if (out->qs < -v->steer_limit) { out->qs = -v->steer_limit; if (out->qsd < 0.0) out->qsd = 0.0; }
+    /* steering servo, implicit damping (the tricycle has no steering joint) */
+    if (!tri) {
+        out->qsd = (v->steer_inertia * a->qsd + dt * (v->steer_kp * (a->u_steer - a->qs))) / (v->steer_inertia + dt * v->steer_damping);
+        out->qs = a->qs + dt * out->qsd;
+        if (out->qs > v->steer_limit) { out->qs = v->steer_limit; if (out->qsd > 0.0) out->qsd = 0.0; }
+        if (out->qs < -v->steer_limit) { out->qs = -v->steer_limit; if (out->qsd < 0.0) out->qsd = 0.0; }
+    }
     /* positions with the new velocities (semi-implicit Euler) */
     out->x = a->x + dt * out->vx;
     out->y = a->y + dt * out->vy;
@@ -748,10 +790,16 @@ int oracle_create(const FtgpConfig *cfg, OracleEnv **out)
         e->spawn[p][2] = cos(ang / 2); e->spawn[p][3] = sin(ang / 2);
     }
     const FtgpVehicle *v = &cfg->vehicle;
-    double a_f = 0.5 * (v->wheel_x[0] + v->wheel_x[1]), a_r = -0.5 * (v->wheel_x[2] + v->wheel_x[3]);
     double wtot = v->mass * v->gravity;
-    e->wheel_load[0] = e->wheel_load[1] = 0.5 * (wtot * (a_r / (a_f + a_r)));
-    e->wheel_load[2] = e->wheel_load[3] = 0.5 * (wtot * (a_f / (a_f + a_r)));
+    if (v->kind == FTGP_VEHICLE_TRICYCLE) {           /* two driven wheels behind the origin, the caster (wheel 2) in front */
+        double a_f = v->wheel_x[2], a_r = -0.5 * (v->wheel_x[0] + v->wheel_x[1]);
+        e->wheel_load[0] = e->wheel_load[1] = 0.5 * (wtot * (a_f / (a_f + a_r)));
+        e->wheel_load[2] = wtot * (a_r / (a_f + a_r)); e->wheel_load[3] = 0.0;
+    } else {
+        double a_f = 0.5 * (v->wheel_x[0] + v->wheel_x[1]), a_r = -0.5 * (v->wheel_x[2] + v->wheel_x[3]);
+        e->wheel_load[0] = e->wheel_load[1] = 0.5 * (wtot * (a_r / (a_f + a_r)));
+        e->wheel_load[2] = e->wheel_load[3] = 0.5 * (wtot * (a_f / (a_f + a_r)));
+    }
     e->n_cars = cfg->n_envs * cfg->cars_per_env;
     e->cars = (Car *)calloc((size_t)e->n_cars, sizeof(Car));
     e->ranges = (float *)calloc((size_t)e->n_cars * R, sizeof(float));

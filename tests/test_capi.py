@@ -31,7 +31,8 @@ def test_struct_layouts_match_the_header(product, oracle):
     # both libraries fill FtgpVehicle through the same C struct: identical bytes => identical layout and constants
     a, b = product.default_vehicle(), oracle.default_vehicle()
     assert bytes(a) == bytes(b)
-    assert C.sizeof(capi.FtgpVehicle) == 8 * 38 and a.softener_radius == pytest.approx(0.03172)
+    assert C.sizeof(capi.FtgpVehicle) == 8 * 41 and a.softener_radius == pytest.approx(0.03172) and a.kind == 0
+    assert bytes(product.tricycle_vehicle()) == bytes(oracle.tricycle_vehicle()) and product.tricycle_vehicle().kind == 1
     assert a.mass == pytest.approx(5.632768) and a.wheel_x[0] == 0.06925 and a.lidar_x == -0.0525
 
 

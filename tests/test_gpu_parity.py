@@ -267,6 +267,25 @@ def test_user_track_from_png_and_svg_on_gpu(product, oracle, tmp_path):
         assert_same_state(g, o)
 
 
+@pytest.mark.parametrize("cars", [1, 3])
+def test_tricycle_vehicle_closed_loop(product, oracle, cars):
+    """f-4: the legacy tricycle of template/car.em.xml (torque motors on two driven wheels, dt 0.0075) as a second vehicle kind:
+    host controls, the random policy and the on-device drivers, GPU vs oracle."""
+    t = load_track("track")
+    v = product.tricycle_vehicle()
+    g, o = both(product, oracle, t, n_envs=24 // cars, cars_per_env=cars, n_rays=90, spawn_mode=1 if cars == 1 else 0, seed=4, dt=0.0075, vehicle=v)
+    with g, o:
+        rng = np.random.default_rng(1)
+        ctrl = np.stack([rng.uniform(-1, 5, g.n_cars), rng.uniform(-1.5, 1.5, g.n_cars)], axis=1)
+        g.set_ctrl(ctrl); o.set_ctrl(ctrl)
+        g.step(300); o.step(300)
+        assert_same_state(g, o)
+        assert np.abs(g.pose()[:, 7:9]).max() > 0.2
+        for policy, steps in (("random", 300), ("nidc", 300)):
+            g.rollout(policy, steps); o.rollout(policy, steps)
+            assert_same_state(g, o)
+
+
 def test_multi_car_env_config5(product, oracle):
     """Config 5: 4 cars per env share a world -- inter-vehicle rays and car-car contact."""
     t = load_track("track")

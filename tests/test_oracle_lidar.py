@@ -31,3 +31,27 @@ def test_f32_spec_vs_binary64_dda(oracle):
         d = np.abs(a.lidar().astype(np.float64) - b.lidar())
         assert (d > 1e-4).mean() < 2e-3           # only rays grazing a pixel corner differ
         assert np.median(d) < 1e-5
+
+
+def test_tricycle_model_drives_and_turns(oracle):
+    """f-4: the legacy differential-drive car (template/car.em.xml, option tricycle_mode): a forward torque accelerates it along
+    its heading, a positive turn torque (right wheel ahead of the left one) yaws it counter-clockwise; controls are clamped to
+    the motors' ctrlrange; the steering joint of the MuSHR model does not exist."""
+    t = load_track("circle")
+    v = oracle.tricycle_vehicle()
+    kw = dict(n_envs=3, n_rays=36, dt=0.0075, vehicle=v)
+    with capi.Env(oracle, t, **kw) as e:
+        p0 = e.pose()
+        yaw0 = e.snapshot()[:, 4]
+        e.set_ctrl(np.array([[1.0, 0.0], [1.0, 0.5], [40.0, 0.0]]))
+        e.step(120)
+        p, yaw = e.pose(), e.snapshot()[:, 4]
+        heading = np.stack([np.cos(yaw0), np.sin(yaw0)], axis=1)
+        along = ((p[:, 0:2] - p0[:, 0:2]) * heading).sum(1)
+        assert (along[[0, 2]] > 0.05).all()                       # moved forward
+        assert abs(np.angle(np.exp(1j * (yaw[0] - yaw0[0])))) < 0.02   # straight without a turn torque
+        assert np.angle(np.exp(1j * (yaw[1] - yaw0[1]))) > 0.1     # turn torque > 0: counter-clockwise
+        with capi.Env(oracle, t, **kw) as f:                       # 40 is clamped to the ctrlrange 4 (car.em.xml:138)
+            f.set_ctrl(np.array([[1.0, 0.0], [1.0, 0.5], [4.0, 0.0]])); f.step(120)
+            np.testing.assert_array_equal(f.pose()[2], p[2])
+        assert (e.pose()[:, 7:9] != 0).any()
