@@ -143,7 +143,7 @@ __device__ __forceinline__ float ray_vs_car(const FtgpVehicle& v, const LidarFra
 // of the wave are finished, their ranges are stored and they take the next rays of the pool together (one LDS atomic
 // per refill, rank among the free lanes via ballot/popcount).  Which lane marches which ray has no influence on any result.
 #ifndef FTGP_REFILL
-#define FTGP_REFILL 48
+#define FTGP_REFILL (MULTI ? 52 : 48)     // measured optimum (tools/ab.sh): the multi-car refill also runs the inter-vehicle tests
 #endif
 // number of set bits of `mask` below this lane
 __device__ __forceinline__ int rank_below(uint64_t mask) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0)); }

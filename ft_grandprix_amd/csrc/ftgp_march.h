@@ -8,8 +8,8 @@
 // same bits.
 //
 // Sector box field.  Both axes are mirrored so that every ray travels towards +x', +y' (x' = -x is exact in IEEE
-// arithmetic and maps cell i to ~i).  Directions are binned into FTGP_SECTORS sectors: the octant (mirror x, mirror y,
-// dominant axis) and, with 16 sectors, whether the slope minor/major is above 1/2.  For each pixel and sector one 16-bit
+// arithmetic and maps cell i to ~i).  Directions are binned into FTGP_SECTORS = 8 * NS sectors: the octant (mirror x, mirror y,
+// dominant axis) and, inside it, NS equal slices of the slope minor/major (NS = 1, 2 or 4).  For each pixel and sector one 16-bit
 // entry holds a box of pixels with its corner at the pixel, extending AHEAD of the ray: low byte kx, high byte ky (cells
 // along x' / y'); 0 = the pixel is a wall.  Only the part of the box that a ray of the sector can reach from anywhere
 // inside the pixel has to be wall-free (the cone of the sector, widened by one cell so that rays through pixel corners --
@@ -29,21 +29,25 @@
 
 #define FTGP_FIELD_OUT 0x0100u
 #ifndef FTGP_SECTORS
-#define FTGP_SECTORS 16
+#define FTGP_SECTORS 32
 #endif
 
-// Entry of pixel (x, y) for sector = (mirror x) | (mirror y) << 1 | (y-dominant) << 2 | (slope > 1/2) << 3.
+#define FTGP_SLOPE_SLICES (FTGP_SECTORS / 8)
+static_assert(FTGP_SECTORS == 8 || FTGP_SECTORS == 16 || FTGP_SECTORS == 32, "8, 16 or 32 sectors");
+
+// Entry of pixel (x, y) for sector = (mirror x) | (mirror y) << 1 | (y-dominant) << 2 | (slope slice) << 3.
 //   runx[d][y][x] wall-free run length starting at the pixel along +x (d = 0) / -x (d = 1); runy likewise
 //                 (0 on walls; 65535 = to the image edge and beyond)
-// In (major A, minor B) coordinates of the sector a ray that starts anywhere in cell (0, 0) with slope in [lo, hi] can
-// only be in row j of column i if  lo * (i - 1) - 1 <= j <= hi * (i + 1) + 1  (closed: corner touches count).  For every
+// In (major A, minor B) coordinates of the sector a ray that starts anywhere in cell (0, 0) with slope in [lo, hi] =
+// [qa / NS, qb / NS] can only be in row j of column i if  lo * (i - 1) - 1 <= j <= hi * (i + 1) + 1  (closed: corner touches count).  For every
 // box height kB the widest admissible kA is the first wall met by the reachable part of rows 0 .. kB - 1; the pair that
 // maximises the travel min(kA, kB / slope) summed over four slopes of the sector is stored.
 FTGP_HD uint32_t ftgp_box_entry(const uint16_t* runx, const uint16_t* runy, int W, int H, int x, int y, int sector)
 {
     const size_t plane = (size_t)W * H;
     if (runx[(size_t)y * W + x] == 0) return 0u;                 // wall
-    const int q = sector & 3, dom = (sector >> 2) & 1, steep = (sector >> 3) & 1;
+    const int q = sector & 3, dom = (sector >> 2) & 1;
+    const int NS = FTGP_SLOPE_SLICES, qa = sector >> 3, qb = qa + 1;
     const int sx = (q & 1) ? -1 : 1, sy = (q & 2) ? -1 : 1;
     const int ax = dom == 0 ? sx : 0, ay = dom == 0 ? 0 : sy;    // unit step along the major / minor axis
     const int bx = dom == 0 ? 0 : sx, by = dom == 0 ? sy : 0;
@@ -51,20 +55,19 @@ FTGP_HD uint32_t ftgp_box_entry(const uint16_t* runx, const uint16_t* runy, int 
     // distance to the image edge: boxes stop there, so that the cell after the box is a ring cell
     const int eX = sx > 0 ? W - x : x + 1, eY = sy > 0 ? H - y : y + 1;
     const int eA = dom == 0 ? eX : eY, eB = dom == 0 ? eY : eX;
-    // sample slopes of the sector, as travel = min(cA * kA, cB[k] * kB) with integer coefficients
-    long cA, cB0, cB1, cB2, cB3;
-    if (FTGP_SECTORS == 8) { cA = 105; cB0 = 840; cB1 = 280; cB2 = 168; cB3 = 120; }                 // 1/8, 3/8, 5/8, 7/8
-    else if (!steep)       { cA = 105; cB0 = 1680; cB1 = 560; cB2 = 336; cB3 = 240; }                // 1/16, 3/16, 5/16, 7/16
-    else                   { cA = 45045; cB0 = 80080; cB1 = 65520; cB2 = 55440; cB3 = 48048; }       // 9/16, 11/16, 13/16, 15/16
+    // four sample slopes n_k / (8 NS), n_k = 8 qa + 1, 3, 5, 7, as travel = min(cA * kA, cB_k * kB) with integer coefficients
+    const long n0 = 8 * qa + 1, n1 = 8 * qa + 3, n2 = 8 * qa + 5, n3 = 8 * qa + 7;
+    const long cA = n0 * n1 * n2 * n3;
+    const long cB0 = 8 * NS * n1 * n2 * n3, cB1 = 8 * NS * n0 * n2 * n3, cB2 = 8 * NS * n0 * n1 * n3, cB3 = 8 * NS * n0 * n1 * n2;
     long best = -1; int bA = 1, bB = 1, m = 65535;
     for (int j = 0; j < 255 && j < eB; ++j) {
-        // first column of row j that a ray of the sector can reach:  j <= hi * (i + 1) + 1
-        int cj = (FTGP_SECTORS == 16 && !steep) ? 2 * j - 3 : j - 2;
+        // first column of row j that a ray of the sector can reach:  j <= hi * (i + 1) + 1  <=>  i >= ceil(NS (j - 1) / qb) - 1
+        int cj = j >= 1 ? (NS * (j - 1) + qb - 1) / qb - 1 : 0;
         cj = cj < 0 ? 0 : cj;
         const int px = x + ax * cj + bx * j, py = y + ay * cj + by * j;
         int lim = 65535;                                          // column of the first wall of the reachable part of row j
         if (px >= 0 && px < W && py >= 0 && py < H) { const int r = run[(size_t)py * W + px]; if (r < 65535) lim = cj + r; }
-        if (FTGP_SECTORS == 16 && steep && lim > 2 * j + 3) lim = 65535;      // ... and the last one: j >= lo * (i - 1) - 1
+        if (qa > 0 && lim > (NS * (j + 1)) / qa + 1) lim = 65535;            // ... and the last one: j >= lo * (i - 1) - 1  <=>  i <= NS (j + 1) / qa + 1
         m = lim < m ? lim : m;
         if (4 * cA * (long)m <= best) break;                      // no taller box can do better
         int kA = m < 255 ? m : 255; kA = kA < eA ? kA : eA;
@@ -131,7 +134,11 @@ FTGP_HD void ftgp_ray_init(FtgpRay& r, float pu, float pv, float du, float dv, f
     r.ivx = ivx; r.ivy = ivy;
     r.s = 0.0f; r.result = -1.0f;
     uint32_t sector = (mx ? 1u : 0u) | (my ? 2u : 0u) | (ydom ? 4u : 0u);
-    if (FTGP_SECTORS == 16) sector |= (2.0f * (ydom ? adu : adv) > (ydom ? adv : adu)) ? 8u : 0u;      // slope minor / major above 1/2
+    {   // slope slice: the number of k in 1 .. NS - 1 with NS * minor > k * major (exact in binary32 for NS <= 4)
+        const float mn = ydom ? adu : adv, mj = ydom ? adv : adu;
+        if (FTGP_SLOPE_SLICES == 2) sector |= (2.0f * mn > mj) ? 8u : 0u;
+        if (FTGP_SLOPE_SLICES == 4) sector |= ((4.0f * mn > mj ? 1u : 0u) + (2.0f * mn > mj ? 1u : 0u) + (4.0f * mn > 3.0f * mj ? 1u : 0u)) << 3;
+    }
     r.mx = mx ? -1 : 0; r.my = my ? -1 : 0;
     r.ix = ix0 ^ r.mx; r.iy = iy0 ^ r.my;
     #if defined(__HIP_DEVICE_COMPILE__)

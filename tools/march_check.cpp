@@ -40,6 +40,7 @@ int main(int argc, char** argv)
     const size_t cells = (size_t)ftgp_plane256(W, H) * 128;
     std::vector<uint16_t> field(cells * FTGP_SECTORS, (uint16_t)FTGP_FIELD_OUT);
     long gw_bad = 0;
+    #pragma omp parallel for collapse(2) schedule(dynamic, 16) reduction(+ : gw_bad)
     for (int oct = 0; oct < FTGP_SECTORS; ++oct)
         for (int y = 0; y < H; ++y)
             for (int x = 0; x < W; ++x) {
