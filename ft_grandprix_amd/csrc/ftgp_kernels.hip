@@ -167,7 +167,6 @@ __device__ __forceinline__ void lidar_pool(const DeviceParams& P, const Lds& L, 
                                            int ncars_here, int ci0, bool scan_lds)
 {
     typedef const __attribute__((address_space(1))) unsigned char* global_u8;
-    typedef const __attribute__((address_space(1))) uint16_t* global_u16;
     typedef __attribute__((address_space(1))) float* global_f32;
     typedef __attribute__((address_space(1))) unsigned char* global_u8w;
     // wave-uniform constants of the sweep, pinned in SGPRs (they come out of the LDS parameter block, i.e. out of VGPRs)
@@ -186,11 +185,12 @@ __device__ __forceinline__ void lidar_pool(const DeviceParams& P, const Lds& L, 
     int cj = -1;                     // (car slot << 16 | ray) of the ray this lane is marching (or has just finished); -1: none
     bool done = true;                // the lane's ray sits on its terminal cell (or the lane has none)
     bool pool_empty = false;         // wave-uniform
+    bool hit = false;                // ... and that cell is a wall (not the ring)
     for (int round = 0; round < (1 << 20); ++round) {
         // ---- finished rays: store the range ...
         if (done && cj >= 0) {
             const int c = cj >> 16, j = cj & 0xffff;
-            float r = ray.result;
+            float r = hit ? fabsf(ray.s) : ray.result;       // ftgp_ray_range()
             if (MULTI) {
                 // Rays also see the other cars of the env (a9).  Conservative cull before the exact box / puck tests: every
                 // visible part of a car lies within `cull` of its origin, so a car whose origin is farther than that from the
@@ -263,16 +263,22 @@ __device__ __forceinline__ void lidar_pool(const DeviceParams& P, const Lds& L, 
         if (!__any(cj >= 0)) break;      // nothing in flight and nothing left to hand out
         // ---- march until enough lanes are free to make a batched refill worthwhile (or, at the end, until all are done)
         const int want = pool_empty ? FTGP_WAVE : FTGP_REFILL;
+        uint64_t live_mask = 0;
+        uint32_t w = FTGP_FIELD_OUT;
         for (int guard = 0; guard < 4 * 8192; ++guard) {
-            const uint32_t w = *(global_u16)(field + (uint32_t)ftgp_ray_offset(ray, fstride));
+            // the entry, zero-extended by the load itself; the wait belongs to it, everything below depends on w
+            asm volatile("global_load_ushort %0, %1, %2\n\ts_waitcnt vmcnt(0)" : "=v"(w) : "v"(ftgp_ray_offset(ray, fstride)), "s"(field));
             FtgpStep st;
             const bool near = ftgp_ray_step(ray, w, eps, st);
+            live_mask = __builtin_amdgcn_ballot_w64(st.live);           // here, next to the comparison: the mask is its result
             int t = st.t;
             if (__any(near)) { const int tf = ftgp_ray_fix(ray, st); t = near ? tf : t; }
             ftgp_ray_commit(ray, st, t);
-            const uint64_t done_mask = __ballot(st.done);
-            if (__popcll(done_mask) >= want) { done = (done_mask >> lane) & 1ull; break; }
+            if (FTGP_WAVE - __popcll(live_mask) >= want) break;
         }
+        // a finished ray has just looked its terminal cell up once more: w is that cell's entry
+        done = !((live_mask >> lane) & 1ull);
+        hit = w == 0u;
     }
 }
 
@@ -466,36 +472,44 @@ __device__ __forceinline__ Force wall_term(const DeviceParams& P, const FtgpVehi
     return t;
 }
 
-// Circles of this car against the circles of the other cars of the env (penalty spring/damper, pre-step states).
-static __device__ __attribute__((noinline)) void car_contact(const DeviceParams& P, const FtgpVehicle& v, const CarCore* me, double ch, double sh,
-                                            const CarCore* env_cars, int my_slot, Force& f)
+// Circles of this car against the circles of the other cars of the env (penalty spring/damper, pre-step states).  Runs on one
+// lane per car between two register-hungry blocks: the loops stay rolled and every operand is re-read from LDS where it is
+// used, so that the only values carried around the loops are the running force and a few indices.
+__device__ __forceinline__ void car_contact(const DeviceParams& P, const FtgpVehicle& v, const CarCore* me, const CarCore* env_cars, int my_slot, Force& f)
 {
-    const double r2 = 2.0 * v.contact_radius;
-    const double sx_ = me->x, sy_ = me->y, svx = me->vx, svy = me->vy, swz = me->wz;
+    #pragma unroll 1
     for (int k = 0; k < P.cars_per_env; ++k) {
         if (k == my_slot || env_cars[k].finished) continue;
         const CarCore* b = env_cars + k;
-        const double bx = b->x, by = b->y, bqw = b->qw, bqz = b->qz, bvx = b->vx, bvy = b->vy, bwz = b->wz;
-        const double cb = 1.0 - 2.0 * (bqz * bqz), sb = 2.0 * (bqw * bqz);
-        for (int i = 0; i < 3; ++i) {
-            const double rxw = ch * v.contact_x[i], ryw = sh * v.contact_x[i];
-            const double px = sx_ + rxw, py = sy_ + ryw;
-            const double vax = svx - swz * ryw, vay = svy + swz * rxw;
-            for (int j = 0; j < 3; ++j) {
-                const double sxw = cb * v.contact_x[j], syw = sb * v.contact_x[j];
-                const double qx = bx + sxw, qy = by + syw;
-                const double ex = px - qx, ey = py - qy;
-                const double d2 = ex * ex + ey * ey;
-                if (d2 >= r2 * r2 || d2 <= 0.0) continue;
-                const double d = sqrt(d2);
-                const double nxv = ex / d, nyv = ey / d;
-                const double vbx = bvx - bwz * syw, vby = bvy + bwz * sxw;
-                const double vn = (vax - vbx) * nxv + (vay - vby) * nyv;
-                const double mag = v.contact_stiffness * (r2 - d) - v.contact_damping * vn;
-                if (mag <= 0.0) continue;
-                const double fx = mag * nxv, fy = mag * nyv;
-                f.fx += fx; f.fy += fy; f.tz += rxw * fy - ryw * fx;
+        #pragma unroll 1
+        for (int ij = 0; ij < 9; ++ij) {
+            FTGP_FORGET_REGISTERS();
+            const int i = ij / 3, j = ij - 3 * i;
+            const double r2 = 2.0 * v.contact_radius;
+            double rxw, ryw, sxw, syw, ex, ey;
+            {
+                const double qw = me->qw, qz = me->qz;
+                const double ch = 1.0 - 2.0 * (qz * qz), sh = 2.0 * (qw * qz);
+                rxw = ch * v.contact_x[i]; ryw = sh * v.contact_x[i];
+                const double bqw = b->qw, bqz = b->qz;
+                const double cb = 1.0 - 2.0 * (bqz * bqz), sb = 2.0 * (bqw * bqz);
+                sxw = cb * v.contact_x[j]; syw = sb * v.contact_x[j];
+                const double px = me->x + rxw, py = me->y + ryw;
+                const double qx = b->x + sxw, qy = b->y + syw;
+                ex = px - qx; ey = py - qy;
             }
+            const double d2 = ex * ex + ey * ey;
+            if (d2 >= r2 * r2 || d2 <= 0.0) continue;
+            const double d = sqrt(d2);
+            const double nxv = ex / d, nyv = ey / d;
+            const double swz = me->wz, bwz = b->wz;
+            const double vax = me->vx - swz * ryw, vay = me->vy + swz * rxw;
+            const double vbx = b->vx - bwz * syw, vby = b->vy + bwz * sxw;
+            const double vn = (vax - vbx) * nxv + (vay - vby) * nyv;
+            const double mag = v.contact_stiffness * (r2 - d) - v.contact_damping * vn;
+            if (mag <= 0.0) continue;
+            const double fx = mag * nxv, fy = mag * nyv;
+            f.fx += fx; f.fy += fy; f.tz += rxw * fy - ryw * fx;
         }
     }
 }
@@ -534,7 +548,6 @@ __device__ __forceinline__ void dynamics_lanes(const DeviceParams& P, const Lds&
     CarCore* st = L.cars + (on ? c : 0);
     Force* terms = L.terms + (on ? c : 0) * FTGP_FORCE_TERMS;
     const FtgpVehicle& v = L.veh->v;
-    const double dt = P.dt;
     const bool finished = st->finished != 0;
     {   // ---- wheel r
         const double qw = st->qw, qz = st->qz;
@@ -542,25 +555,30 @@ __device__ __forceinline__ void dynamics_lanes(const DeviceParams& P, const Lds&
         const double vx = st->vx, vy = st->vy, wz = st->wz;
         // Ackermann coupling, mushr.em.xml:185-186: q + 0.375 q^2 + 0.140625 q^3 - 0.0722656 q^4 (fl), the odd signs flipped for fr
         const double q = st->qs;
-        const double c1 = (r == 0) ? 0.375 : -0.375, c3 = (r == 0) ? -0.0722656 : 0.0722656;
-        const double steer = q * (1.0 + q * (c1 + q * (0.140625 + q * c3)));
-        const bool tri = v.kind == FTGP_VEHICLE_TRICYCLE;               // legacy differential-drive car (car.em.xml): no steering, two driven wheels
+        // (the odd coefficients by sign flips of the products: a negation is exact, and no 64-bit constant has to be selected per lane)
+        const double c1 = (r == 0) ? 0.375 : -0.375;
+        const double q4 = q * 0.0722656, t3 = (r == 0) ? -q4 : q4;
+        const double steer = q * (1.0 + q * (c1 + q * (0.140625 + t3)));
+        const bool tri = sgpr(v.kind) == FTGP_VEHICLE_TRICYCLE;         // legacy differential-drive car (car.em.xml): no steering, two driven wheels
         const double ang = (!tri && r < 2) ? steer : 0.0;               // wheels that do not steer: the polynomials give exactly (1, 0) at 0
         const double cwi = spec_cos(ang), swi = spec_sin(ang);
-        // velocity servo on the tendon = mean wheel spin, mushr.em.xml:180,191-196
-        const double wbar = 0.25 * (((st->w[0] + st->w[1]) + st->w[2]) + st->w[3]);
-        double fa = v.throttle_kv * (st->u_speed - v.throttle_gear * wbar);
-        if (fa > v.throttle_force_limit) fa = v.throttle_force_limit;
-        if (fa < -v.throttle_force_limit) fa = -v.throttle_force_limit;
-        const double ta = (v.throttle_gear * 0.25) * fa;
-        // tricycle: two torque motors on the tendons 0.5 (l + r) and 0.5 (r - l), controls clamped to their ctrlrange (car.em.xml:126-139)
-        double uf = st->u_speed, ut = st->u_steer;
-        if (uf > v.motor_forward_limit) uf = v.motor_forward_limit;
-        if (uf < -v.motor_forward_limit) uf = -v.motor_forward_limit;
-        if (ut > v.motor_turn_limit) ut = v.motor_turn_limit;
-        if (ut < -v.motor_turn_limit) ut = -v.motor_turn_limit;
-        const double tl = 0.5 * uf - 0.5 * ut, tr = 0.5 * uf + 0.5 * ut;
-        const double torque = tri ? (r == 0 ? tl : tr) : ta;
+        double torque;
+        if (!tri) {
+            // velocity servo on the tendon = mean wheel spin, mushr.em.xml:180,191-196
+            const double wbar = 0.25 * (((st->w[0] + st->w[1]) + st->w[2]) + st->w[3]);
+            double fa = v.throttle_kv * (st->u_speed - v.throttle_gear * wbar);
+            if (fa > v.throttle_force_limit) fa = v.throttle_force_limit;
+            if (fa < -v.throttle_force_limit) fa = -v.throttle_force_limit;
+            torque = (v.throttle_gear * 0.25) * fa;
+        } else {
+            // two torque motors on the tendons 0.5 (l + r) and 0.5 (r - l), controls clamped to their ctrlrange (car.em.xml:126-139)
+            double uf = st->u_speed, ut = st->u_steer;
+            if (uf > v.motor_forward_limit) uf = v.motor_forward_limit;
+            if (uf < -v.motor_forward_limit) uf = -v.motor_forward_limit;
+            if (ut > v.motor_turn_limit) ut = v.motor_turn_limit;
+            if (ut < -v.motor_turn_limit) ut = -v.motor_turn_limit;
+            torque = (r == 0) ? 0.5 * uf - 0.5 * ut : 0.5 * uf + 0.5 * ut;
+        }
         const bool rolling = !(tri && r >= 2);                          // the caster is frictionless and there is no fourth wheel
         const double wi = st->w[r];
         const double wx_ = v.wheel_x[r], wy_ = v.wheel_y[r];
@@ -576,6 +594,7 @@ __device__ __forceinline__ void dynamics_lanes(const DeviceParams& P, const Lds&
         if (m2 > lim * lim) { const double sc = lim / sqrt(m2); flong = flong * sc; flat = flat * sc; }
         Force t;
         t.fx = flong * fdx - flat * fdy; t.fy = flong * fdy + flat * fdx; t.tz = rxw * t.fy - ryw * t.fx;
+        const double dt = P.dt;
         const double wn = (v.wheel_inertia * wi + dt * (torque - v.wheel_radius * flong)) / (v.wheel_inertia + dt * v.wheel_damping);
         if (!rolling) { t.fx = 0.0; t.fy = 0.0; t.tz = 0.0; }
         if (on) { terms[r] = t; L.wnew[(on ? c : 0) * 4 + r] = rolling ? wn : wi; }
@@ -597,10 +616,8 @@ __device__ __forceinline__ void dynamics_lanes(const DeviceParams& P, const Lds&
         #pragma unroll 1
         for (int k = 0; k < FTGP_FORCE_TERMS; ++k) { const Force t = terms[k]; f.fx += t.fx; f.fy += t.fy; f.tz += t.tz; }
         const double qw = st->qw, qz = st->qz;
-        if (MULTI && !finished) {
-            const double ch = 1.0 - 2.0 * (qz * qz), sh = 2.0 * (qw * qz);
-            car_contact(P, v, st, ch, sh, L.cars + (c - c % P.cars_per_env), c % P.cars_per_env, f);
-        }
+        if (MULTI && !finished) car_contact(P, v, st, L.cars + (c - c % P.cars_per_env), c % P.cars_per_env, f);
+        const double dt = P.dt;
         Dyn o;
         o.vx = st->vx + dt * (f.fx / v.mass);
         o.vy = st->vy + dt * (f.fy / v.mass);

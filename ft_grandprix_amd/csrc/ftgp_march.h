@@ -99,7 +99,7 @@ FTGP_HD float ftgp_snap_eps(int W, int H)
 // byte offset of its entry = offC + 2 * ((iy ^ my) * fstride + (ix ^ mx)), offC = start of the sector's plane + the ring.
 struct FtgpRay {
     float pum, pvm, dum, dvm, ivx, ivy;   // mirrored origin, |direction|, |1 / direction| (+inf where the direction is 0)
-    float s, result;                      // crossing time of the last step; range (-1: none yet / off the image)
+    float s, result;                      // crossing time of the last step; range when the ray ends on no wall (-1, see ftgp_ray_range)
     int ix, iy;                           // mirrored cell
     int offC, mx, my;
 };
@@ -158,7 +158,7 @@ FTGP_HD int ftgp_ray_offset(const FtgpRay& r, int fstride)
 #endif
 }
 
-struct FtgpStep { float sn; int t, cur, hi, xe, ye; bool stepx, done; };
+struct FtgpStep { float sn; int t, cur, hi, xe, ye; bool stepx, live; };       // live: the ray is not on its terminal cell yet
 
 // One generic iteration, first half: w is the field entry of the ray's cell.  Jumps to the far edge of the box
 // (s = min(sX, sY) of its exit boundaries) and estimates the transverse cell as floor(p + d * s).  Returns true when the
@@ -170,13 +170,12 @@ FTGP_HD bool ftgp_ray_step(FtgpRay& r, uint32_t w, float eps, FtgpStep& st)
     // entry (SDWA), floor-and-convert in one instruction, hardware fract, three-operand median for the clamp
     asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(st.xe) : "v"(r.ix), "v"(w));
     asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(st.ye) : "v"(r.iy), "v"(w));
-    st.done = st.xe == r.ix;                                  // kx == 0: wall or ring cell
+    st.live = st.xe != r.ix;                                  // kx == 0: wall or ring cell
 #else
-    const int kx = (int)(w & 255u), ky = (int)(w >> 8);
-    st.done = kx == 0;                                        // wall or ring cell
+    const int kx = (int)(w & 255u), ky = (int)(w >> 8) & 255;
+    st.live = kx != 0;                                        // kx == 0: wall or ring cell
     st.xe = r.ix + kx; st.ye = r.iy + ky;
 #endif
-    r.result = (w == 0u) ? fabsf(r.s) : r.result;             // |s|: a ray that starts on a boundary can produce -0
     const float sX = ((float)st.xe - r.pum) * r.ivx;
     const float sY = ((float)st.ye - r.pvm) * r.ivy;
     st.stepx = sX < sY;
@@ -196,7 +195,7 @@ FTGP_HD bool ftgp_ray_step(FtgpRay& r, uint32_t w, float eps, FtgpStep& st)
     st.t = t;
     const float frac = v - fl;
 #endif
-    return !st.done & (fabsf(frac - 0.5f) > 0.5f - eps);    // within eps of a boundary (and never for a NaN)
+    return st.live & (fabsf(frac - 0.5f) > 0.5f - eps);    // within eps of a boundary (and never for a NaN)
 }
 
 // the specification's comparisons for a landing point close to a boundary (sY(b) <= s after an x-jump, sX(b) < s after a y-jump)
@@ -214,9 +213,13 @@ FTGP_HD int ftgp_ray_fix(const FtgpRay& r, const FtgpStep& st)
 FTGP_HD void ftgp_ray_commit(FtgpRay& r, const FtgpStep& st, int t)
 {
     const int nix = st.stepx ? st.xe : t, niy = st.stepx ? t : st.ye;
-    r.ix = st.done ? r.ix : nix; r.iy = st.done ? r.iy : niy;     // a finished ray stays on its terminal cell
-    r.s = st.done ? r.s : st.sn;
+    r.ix = st.live ? nix : r.ix; r.iy = st.live ? niy : r.iy;     // a finished ray stays on its terminal cell
+    r.s = st.live ? st.sn : r.s;
 }
+
+// Range of a ray that sits on its terminal cell, whose entry is w: the crossing time into a wall cell, `result` (-1, or 0 for a
+// switched-off rangefinder) on a ring cell.  |s|: a ray that starts on a boundary can produce -0.
+FTGP_HD float ftgp_ray_range(const FtgpRay& r, uint32_t w) { return w == 0u ? fabsf(r.s) : r.result; }
 
 // single ray against a field image (host harness, tests)
 FTGP_HD float ftgp_march_one(const uint16_t* field, int W, int H, float eps, float pu, float pv, float du, float dv)
@@ -224,13 +227,14 @@ FTGP_HD float ftgp_march_one(const uint16_t* field, int W, int H, float eps, flo
     const int fstride = W + 2;
     const uint32_t plane256 = ftgp_plane256(W, H);
     FtgpRay r; ftgp_ray_init(r, pu, pv, du, dv, fabsf(1.0f / du), fabsf(1.0f / dv), W, H, fstride, plane256);
+    uint32_t w = FTGP_FIELD_OUT;
     for (int guard = 0; guard < 4 * 8192; ++guard) {
-        const uint32_t w = field[ftgp_ray_offset(r, fstride) >> 1];
+        w = field[ftgp_ray_offset(r, fstride) >> 1];
         FtgpStep st;
         const bool near = ftgp_ray_step(r, w, eps, st);
         const int t = near ? ftgp_ray_fix(r, st) : st.t;
         ftgp_ray_commit(r, st, t);
-        if (st.done) break;
+        if (!st.live) return ftgp_ray_range(r, w);
     }
     return r.result;
 }

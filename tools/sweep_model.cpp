@@ -110,7 +110,7 @@ int main(int argc, char** argv)
                         const int t = near ? ftgp_ray_fix(l.r, st) : st.t;
                         ftgp_ray_commit(l.r, st, t);
                         if (!l.done || l.g >= 0) lane_iters += !l.done;
-                        l.done = st.done; ndone += st.done;
+                        l.done = (!st.live); ndone += (!st.live);
                     }
                     std::sort(lineset.begin(), lineset.end()); lines += std::unique(lineset.begin(), lineset.end()) - lineset.begin();
                     ++wave_iters; ++witers[w]; fixes += anynear;
