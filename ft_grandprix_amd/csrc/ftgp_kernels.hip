@@ -143,7 +143,7 @@ __device__ __forceinline__ float ray_vs_car(const FtgpVehicle& v, const LidarFra
 // of the wave are finished, their ranges are stored and they take the next rays of the pool together (one LDS atomic
 // per refill, rank among the free lanes via ballot/popcount).  Which lane marches which ray has no influence on any result.
 #ifndef FTGP_REFILL
-#define FTGP_REFILL (MULTI ? 52 : 48)     // measured optimum (tools/ab.sh): the multi-car refill also runs the inter-vehicle tests
+#define FTGP_REFILL (MULTI ? 56 : 48)     // measured optimum (tools/ab.sh): the multi-car refill also runs the inter-vehicle tests
 #endif
 // number of set bits of `mask` below this lane
 __device__ __forceinline__ int rank_below(uint64_t mask) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0)); }
@@ -267,7 +267,7 @@ __device__ __forceinline__ void lidar_pool(const DeviceParams& P, const Lds& L, 
         uint32_t w = FTGP_FIELD_OUT;
         for (int guard = 0; guard < 4 * 8192; ++guard) {
             // the entry, zero-extended by the load itself; the wait belongs to it, everything below depends on w
-            asm volatile("global_load_ushort %0, %1, %2\n\ts_waitcnt vmcnt(0)" : "=v"(w) : "v"(ftgp_ray_offset(ray, fstride)), "s"(field));
+            asm volatile("global_load_ushort %0, %1, %2\n\ts_waitcnt vmcnt(0)" : "=v"(w) : "v"(ftgp_ray_offset(ray)), "s"(field));
             FtgpStep st;
             const bool near = ftgp_ray_step(ray, w, eps, st);
             live_mask = __builtin_amdgcn_ballot_w64(st.live);           // here, next to the comparison: the mask is its result

@@ -95,13 +95,14 @@ FTGP_HD float ftgp_snap_eps(int W, int H)
     return (float)p * (1.0f / 2097152.0f);
 }
 
-// One ray in the mirrored frame.  mx / my (0 or -1) turn the mirrored cell back into the true pixel (ix ^ mx, iy ^ my);
-// byte offset of its entry = offC + 2 * ((iy ^ my) * fstride + (ix ^ mx)), offC = start of the sector's plane + the ring.
+// One ray in the mirrored frame.  A mirrored coordinate is the complement of the true one (ix = ~x = -x - 1), so the byte offset of
+// the entry of cell (ix, iy) is linear in it:  offC + ix * ax + iy * ay  with ax = +-2, ay = +-2 * fstride and offC = start of
+// the sector's plane + the ring + the two constants of the complements.
 struct FtgpRay {
     float pum, pvm, dum, dvm, ivx, ivy;   // mirrored origin, |direction|, |1 / direction| (+inf where the direction is 0)
     float s, result;                      // crossing time of the last step; range when the ray ends on no wall (-1, see ftgp_ray_range)
     int ix, iy;                           // mirrored cell
-    int offC, mx, my;
+    int offC, ax, ay;
 };
 
 // A ray that marches nothing: it sits on ring cell (0, 0) of plane 0, which terminates at once and leaves `result` alone.
@@ -109,7 +110,7 @@ FTGP_HD void ftgp_ray_park(FtgpRay& r, float result)
 {
     r.pum = r.pvm = r.dum = r.dvm = r.ivx = r.ivy = 0.0f;
     r.s = 0.0f; r.result = result;
-    r.ix = r.iy = 0; r.offC = 0; r.mx = r.my = 0;
+    r.ix = r.iy = 0; r.offC = 0; r.ax = r.ay = 0;
 }
 
 // fstride = W + 2 (cells per plane row); plane256 = bytes per sector plane / 256 (planes are padded to a multiple of 256 B);
@@ -139,22 +140,29 @@ FTGP_HD void ftgp_ray_init(FtgpRay& r, float pu, float pv, float du, float dv, f
         if (FTGP_SLOPE_SLICES == 2) sector |= (2.0f * mn > mj) ? 8u : 0u;
         if (FTGP_SLOPE_SLICES == 4) sector |= ((4.0f * mn > mj ? 1u : 0u) + (2.0f * mn > mj ? 1u : 0u) + (4.0f * mn > 3.0f * mj ? 1u : 0u)) << 3;
     }
-    r.mx = mx ? -1 : 0; r.my = my ? -1 : 0;
-    r.ix = ix0 ^ r.mx; r.iy = iy0 ^ r.my;
-    #if defined(__HIP_DEVICE_COMPILE__)
-    r.offC = (int)((__umul24(sector, plane256) << 8) + 2u * (uint32_t)(fstride + 1));       // plane256 < 2^24
+    const int mxm = mx ? -1 : 0, mym = my ? -1 : 0, F = 2 * fstride;
+    r.ix = ix0 ^ mxm; r.iy = iy0 ^ mym;
+    r.ax = 2 + 4 * mxm; r.ay = (F ^ mym) - mym;               // +-2, +-F
+    // 2 * (x + 1) = ix * ax + (ax + 2) / 2 - ... : both complements cost half their stride, hence (ax + ay) / 2 (exact, both even)
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t plane;                                           // plane256 < 2^24; spelled out, or the shift below is folded into a 32-bit multiply
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(plane) : "v"(sector), "s"(plane256));
 #else
-    r.offC = (int)(((sector * plane256) << 8) + 2u * (uint32_t)(fstride + 1));
+    const uint32_t plane = sector * plane256;
 #endif
-    if (!inside) { r.ix = r.iy = 0; r.offC = 0; r.mx = r.my = 0; }       // starts off the image: ring cell (0, 0), result stays -1
+    r.offC = (int)(plane << 8) + (fstride + 1) + ((r.ax + r.ay) >> 1);
+    if (!inside) { r.ix = r.iy = 0; r.offC = 0; r.ax = r.ay = 0; }       // starts off the image: ring cell (0, 0), result stays -1
 }
 
-FTGP_HD int ftgp_ray_offset(const FtgpRay& r, int fstride)
+FTGP_HD int ftgp_ray_offset(const FtgpRay& r)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return r.offC + 2 * (__mul24(r.iy ^ r.my, fstride) + (r.ix ^ r.mx));
+    int a, b;                                                 // two multiply-adds (the compiler prefers two multiplies and a three-operand add)
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(a) : "v"(r.iy), "v"(r.ay), "v"(r.offC));
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(b) : "v"(r.ix), "v"(r.ax), "v"(a));
+    return b;
 #else
-    return r.offC + 2 * ((r.iy ^ r.my) * fstride + (r.ix ^ r.mx));
+    return r.ix * r.ax + (r.iy * r.ay + r.offC);
 #endif
 }
 
@@ -180,8 +188,17 @@ FTGP_HD bool ftgp_ray_step(FtgpRay& r, uint32_t w, float eps, FtgpStep& st)
     const float sY = ((float)st.ye - r.pvm) * r.ivy;
     st.stepx = sX < sY;
     st.sn = st.stepx ? sX : sY;
-    const float tp = st.stepx ? r.pvm : r.pum, td = st.stepx ? r.dvm : r.dum;
-    const float v = fmaf(td, st.sn, tp);
+    // both landing estimates, then the one that applies: fma(dvm, sX, pvm) after an x-jump, fma(dum, sY, pum) after a y-jump
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 d2 = { r.dum, r.dvm }, p2 = { r.pum, r.pvm }, s2 = { sX, sY };
+    f32x2 v2;                                                 // one packed fma with the halves of d and p swapped
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,1] op_sel_hi:[0,1,0]" : "=v"(v2) : "v"(d2), "v"(s2), "v"(p2));
+    const float vX = v2.x, vY = v2.y;
+#else
+    const float vX = fmaf(r.dvm, sX, r.pvm), vY = fmaf(r.dum, sY, r.pum);
+#endif
+    const float v = st.stepx ? vX : vY;
     st.cur = st.stepx ? r.iy : r.ix; st.hi = (st.stepx ? st.ye : st.xe) - 1;
 #if defined(__HIP_DEVICE_COMPILE__)
     int t;
@@ -229,7 +246,7 @@ FTGP_HD float ftgp_march_one(const uint16_t* field, int W, int H, float eps, flo
     FtgpRay r; ftgp_ray_init(r, pu, pv, du, dv, fabsf(1.0f / du), fabsf(1.0f / dv), W, H, fstride, plane256);
     uint32_t w = FTGP_FIELD_OUT;
     for (int guard = 0; guard < 4 * 8192; ++guard) {
-        w = field[ftgp_ray_offset(r, fstride) >> 1];
+        w = field[ftgp_ray_offset(r) >> 1];
         FtgpStep st;
         const bool near = ftgp_ray_step(r, w, eps, st);
         const int t = near ? ftgp_ray_fix(r, st) : st.t;

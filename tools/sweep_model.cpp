@@ -102,7 +102,7 @@ int main(int argc, char** argv)
                     bool anynear = false; int ndone = 0;
                     std::vector<int> lineset;
                     for (auto& l : L) {
-                        const int off = ftgp_ray_offset(l.r, fstride);
+                        const int off = ftgp_ray_offset(l.r);
                         lineset.push_back(off >> 7);
                         const uint32_t wq = field[off >> 1];
                         FtgpStep st; const bool near = ftgp_ray_step(l.r, wq, eps, st);
