@@ -180,7 +180,7 @@ void build_cover_table(double car_width, int n_rays, int kmax, float* thr)
 int lds_layout(DeviceParams& P, int cpb, int wpb)
 {
     int o = 0;
-    P.off_params = o; o += pad16(sizeof(DeviceParams));
+    P.off_params = o; o += pad16(offsetof(DeviceParams, veh));              // the head of the block: what the step kernel reads
     P.off_veh = o;    o += pad16(sizeof(VehLds));
     P.off_path = o;   o += pad16(sizeof(double) * 2 * FTGP_PATH_POINTS);
     P.off_ray = o;    o += pad16(sizeof(float) * 2 * (size_t)P.n_rays);
@@ -188,9 +188,9 @@ int lds_layout(DeviceParams& P, int cpb, int wpb)
     P.off_frame = o;  o += 2 * cpb * (int)sizeof(LidarFrame);      // double-buffered by step parity
     P.off_steps = o;  o += pad16((size_t)cpb * sizeof(int64_t));
     P.off_scan = o;   o += 2 * cpb * P.win_floats * (int)sizeof(float);   // double-buffered by step parity
-    P.off_list = o;   o += wpb * FTGP_WAVE * (int)sizeof(int);
+    P.off_list = o;   o += std::min(cpb, wpb) * FTGP_WAVE * (int)sizeof(int);                 // driver scratch: wave c runs the driver of car c
     P.off_pool = o;   o += 16;
-    P.off_k1 = o;     o += FTGP_MAX_CARS_PER_BLOCK * (FTGP_FORCE_TERMS * 24 + 4 * 8 + 104);      // K1 staging: force terms | new wheel spins | new state
+    P.off_k1 = o;     o += cpb * (FTGP_FORCE_TERMS * 24 + 4 * 8 + 104);                         // K1 staging: force terms | new wheel spins | new state
     P.off_cover = o;  o += pad16(sizeof(float) * (size_t)(P.cover_kmax + 1));             // cover-count thresholds of the launch's driver (last: its size = lds_bytes - off_cover)
     P.lds_bytes = o;
     P.cars_per_block = cpb; P.waves_per_block = wpb;
@@ -431,6 +431,8 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
             ftgp_destroy(e);
             return FTGP_ERR_ARG;
         }
+        if (getenv("FTGP_VERBOSE"))
+            fprintf(stderr, "ftgp_create: %d cars x %d waves per workgroup, %d B of LDS (cap %d)\n", cpb, wpb, lds_layout(P, cpb, wpb), lds_cap);
         // pool index -> car slot by multiplication: exact for every index the sweep can produce
         for (uint32_t g = 0; g < (uint32_t)(cpb * P.n_rays); ++g)
             if ((uint32_t)(((uint64_t)g * P.ray_magic) >> 32) != g / (uint32_t)P.n_rays) {

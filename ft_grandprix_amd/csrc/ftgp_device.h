@@ -68,7 +68,7 @@ struct DeviceParams {
     CarState* cars;
     float* ranges;                // [n_cars][ranges_stride]
     int64_t* steps;               // [n_envs]
-    FtgpVehicle veh;              // host-side copy (kernels read the LDS image)
+    FtgpVehicle veh;              // host-side copy (the step kernel reads the LDS image VehLds; from here on nothing is staged into LDS)
     double wheel_load[4];
 };
 

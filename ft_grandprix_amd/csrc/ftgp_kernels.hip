@@ -58,14 +58,14 @@ __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+s"(v)); retur
 // that needs them instead of being hoisted in front of the step loop and carried -- spilled -- across the sweep
 __device__ __forceinline__ int lane_here() { int l = lane_id(); asm volatile("" : "+v"(l)); return l; }
 
-struct LdsOffsets { int params, veh, path, ray, cars, frame, steps, scan, list, pool, k1, cover; };
+struct LdsOffsets { int params, veh, path, ray, cars, frame, steps, scan, list, pool, k1, cover, cpb; };
 
 __device__ __forceinline__ LdsOffsets lds_offsets(const DeviceParams& P)
 {
     LdsOffsets o;
     o.params = sgpr(P.off_params); o.veh = sgpr(P.off_veh); o.path = sgpr(P.off_path); o.ray = sgpr(P.off_ray); o.cars = sgpr(P.off_cars);
     o.frame = sgpr(P.off_frame); o.steps = sgpr(P.off_steps); o.scan = sgpr(P.off_scan); o.list = sgpr(P.off_list); o.pool = sgpr(P.off_pool);
-    o.k1 = sgpr(P.off_k1); o.cover = sgpr(P.off_cover);
+    o.k1 = sgpr(P.off_k1); o.cover = sgpr(P.off_cover); o.cpb = sgpr(P.cars_per_block);
     return o;
 }
 
@@ -83,8 +83,8 @@ __device__ __forceinline__ Lds lds_view(const LdsOffsets& o, unsigned char* lds)
     L.pool = reinterpret_cast<int*>(lds + opaque(o.pool));
     unsigned char* k1 = lds + opaque(o.k1);     // one block: terms | wnew | next (sizes follow from cars_per_block)
     L.terms = reinterpret_cast<Force*>(k1);
-    L.wnew = reinterpret_cast<double*>(k1 + FTGP_MAX_CARS_PER_BLOCK * FTGP_FORCE_TERMS * sizeof(Force));
-    L.next = reinterpret_cast<Dyn*>(k1 + FTGP_MAX_CARS_PER_BLOCK * (FTGP_FORCE_TERMS * sizeof(Force) + 4 * sizeof(double)));
+    L.wnew = reinterpret_cast<double*>(k1 + o.cpb * (int)(FTGP_FORCE_TERMS * sizeof(Force)));
+    L.next = reinterpret_cast<Dyn*>(k1 + o.cpb * (int)(FTGP_FORCE_TERMS * sizeof(Force) + 4 * sizeof(double)));
     L.cover = reinterpret_cast<const float*>(lds + opaque(o.cover));
     return L;
 }
@@ -142,6 +142,9 @@ __device__ __forceinline__ float ray_vs_car(const FtgpVehicle& v, const LidarFra
 // finished ray idles on its terminal cell, so the loop body has no active-lane predication); as soon as FTGP_REFILL lanes
 // of the wave are finished, their ranges are stored and they take the next rays of the pool together (one LDS atomic
 // per refill, rank among the free lanes via ballot/popcount).  Which lane marches which ray has no influence on any result.
+#ifndef FTGP_MASK_IDLE_LOADS
+#define FTGP_MASK_IDLE_LOADS 1
+#endif
 #ifndef FTGP_REFILL
 #define FTGP_REFILL (MULTI ? 56 : 48)     // measured optimum (tools/ab.sh): the multi-car refill also runs the inter-vehicle tests
 #endif
@@ -162,9 +165,23 @@ __device__ __forceinline__ float rcp_abs(float x)
     return y;
 }
 
+// diagnostic build only (tools/stamps.sh): per-phase shader-clock totals over all workgroups and steps; never in the product
+#ifdef FTGP_STAMPS
+__device__ unsigned long long ftgp_stamps[16];
+#define STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define STAMP_ADD(slot, dt) stamp_acc[slot] += (unsigned long long)(dt)
+#define STAMP_ARG , unsigned long long* stamp_acc
+#define STAMP_PASS , stamp_acc
+#else
+#define STAMP(var) do {} while (0)
+#define STAMP_ADD(slot, dt) do {} while (0)
+#define STAMP_ARG
+#define STAMP_PASS
+#endif
+
 template <bool MULTI>
 __device__ __forceinline__ void lidar_pool(const DeviceParams& P, const Lds& L, const LidarFrame* frames, float* scan_rows, int* pool,
-                                           int ncars_here, int ci0, bool scan_lds)
+                                           int ncars_here, int ci0, bool scan_lds STAMP_ARG)
 {
     typedef const __attribute__((address_space(1))) unsigned char* global_u8;
     typedef __attribute__((address_space(1))) float* global_f32;
@@ -187,6 +204,7 @@ __device__ __forceinline__ void lidar_pool(const DeviceParams& P, const Lds& L, 
     bool pool_empty = false;         // wave-uniform
     bool hit = false;                // ... and that cell is a wall (not the ring)
     for (int round = 0; round < (1 << 20); ++round) {
+        STAMP(ta);
         // ---- finished rays: store the range ...
         if (done && cj >= 0) {
             const int c = cj >> 16, j = cj & 0xffff;
@@ -261,21 +279,31 @@ __device__ __forceinline__ void lidar_pool(const DeviceParams& P, const Lds& L, 
             pool_empty = base + nfree >= total;
         }
         if (!__any(cj >= 0)) break;      // nothing in flight and nothing left to hand out
+        STAMP(tb); STAMP_ADD(8, tb - ta); STAMP_ADD(9, 1);
         // ---- march until enough lanes are free to make a batched refill worthwhile (or, at the end, until all are done)
         const int want = pool_empty ? FTGP_WAVE : FTGP_REFILL;
         uint64_t live_mask = 0;
         uint32_t w = FTGP_FIELD_OUT;
+        bool alive = cj >= 0;            // lanes whose ray is known to sit on its terminal cell keep that cell's entry and issue no load
         for (int guard = 0; guard < 4 * 8192; ++guard) {
             // the entry, zero-extended by the load itself; the wait belongs to it, everything below depends on w
+#if FTGP_MASK_IDLE_LOADS
+            if (alive)
+                asm volatile("global_load_ushort %0, %1, %2\n\ts_waitcnt vmcnt(0)" : "+v"(w) : "v"(ftgp_ray_offset(ray)), "s"(field));
+#else
             asm volatile("global_load_ushort %0, %1, %2\n\ts_waitcnt vmcnt(0)" : "=v"(w) : "v"(ftgp_ray_offset(ray)), "s"(field));
+#endif
             FtgpStep st;
             const bool near = ftgp_ray_step(ray, w, eps, st);
             live_mask = __builtin_amdgcn_ballot_w64(st.live);           // here, next to the comparison: the mask is its result
             int t = st.t;
             if (__any(near)) { const int tf = ftgp_ray_fix(ray, st); t = near ? tf : t; }
             ftgp_ray_commit(ray, st, t);
+            alive = st.live;
+            STAMP_ADD(11, 1);
             if (FTGP_WAVE - __popcll(live_mask) >= want) break;
         }
+        STAMP(tc); STAMP_ADD(10, tc - tb);
         // a finished ray has just looked its terminal cell up once more: w is that cell's entry
         done = !((live_mask >> lane) & 1ull);
         hit = w == 0u;
@@ -834,16 +862,6 @@ __device__ __forceinline__ void stage16(void* dst, const void* src, int bytes)
     for (int i = threadIdx.x; i < n; i += blockDim.x) d4[i] = s4[i];
 }
 
-// diagnostic build only (tools/stamps.sh): per-phase shader-clock totals over all workgroups and steps; never in the product
-#ifdef FTGP_STAMPS
-__device__ unsigned long long ftgp_stamps[16];
-#define STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
-#define STAMP_ADD(slot, dt) stamp_acc[slot] += (unsigned long long)(dt)
-#else
-#define STAMP(var) do {} while (0)
-#define STAMP_ADD(slot, dt) do {} while (0)
-#endif
-
 #ifndef FTGP_WAVES_PER_EU
 #define FTGP_WAVES_PER_EU 8       // two 16-wave workgroups per CU: at most 64 VGPRs per lane
 #endif
@@ -898,7 +916,7 @@ __global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(cons
     // The scan a driver sees lags the pose by one step (custom.py:1395-1425), which is what makes this legal: the sweep of
     // step t needs only the pose of step t, and that depends on the controls of step t-1.
 #ifdef FTGP_STAMPS
-    unsigned long long stamp_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    unsigned long long stamp_acc[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 #endif
     for (int it = 0; it < n_steps; ++it) {
         STAMP(t0);
@@ -936,7 +954,7 @@ __global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(cons
 #endif
         STAMP(t3);
 #ifndef FTGP_ABLATE_K2
-        lidar_pool<MULTI>(P, L, frames, scan_now, L.pool + par, ncars_here, ci0, need_scan);
+        lidar_pool<MULTI>(P, L, frames, scan_now, L.pool + par, ncars_here, ci0, need_scan STAMP_PASS);
 #endif
         STAMP(t4);
         __syncthreads();
@@ -945,7 +963,7 @@ __global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(cons
     }
 
 #ifdef FTGP_STAMPS
-    if (lane == 0) for (int q = 0; q < 8; ++q) atomicAdd(&ftgp_stamps[q], stamp_acc[q]);
+    if (lane == 0) for (int q = 0; q < 12; ++q) atomicAdd(&ftgp_stamps[q], stamp_acc[q]);
 #endif
     const DeviceParams& P = P0;
     const Lds L = lds_view(off, lds);

@@ -189,15 +189,9 @@ FTGP_HD bool ftgp_ray_step(FtgpRay& r, uint32_t w, float eps, FtgpStep& st)
     st.stepx = sX < sY;
     st.sn = st.stepx ? sX : sY;
     // both landing estimates, then the one that applies: fma(dvm, sX, pvm) after an x-jump, fma(dum, sY, pum) after a y-jump
-#if defined(__HIP_DEVICE_COMPILE__)
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    const f32x2 d2 = { r.dum, r.dvm }, p2 = { r.pum, r.pvm }, s2 = { sX, sY };
-    f32x2 v2;                                                 // one packed fma with the halves of d and p swapped
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,1] op_sel_hi:[0,1,0]" : "=v"(v2) : "v"(d2), "v"(s2), "v"(p2));
-    const float vX = v2.x, vY = v2.y;
-#else
+    // (two scalar fmas: packed binary32 instructions cost more than two scalar ones on gfx950, measured -- the library is
+    // also built with -fno-slp-vectorize for that reason)
     const float vX = fmaf(r.dvm, sX, r.pvm), vY = fmaf(r.dum, sY, r.pum);
-#endif
     const float v = st.stepx ? vX : vY;
     st.cur = st.stepx ? r.iy : r.ix; st.hi = (st.stepx ? st.ye : st.xe) - 1;
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -4,7 +4,7 @@ set -u
 cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp
 tag=$1
 rm -rf gpurun_out/l2_$tag
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCP_TCC_READ_REQ_sum --output-format csv -d gpurun_out/l2_$tag -- python3 tools/prof_case.py 4096 1080 fast 500 > gpurun_out/l2_$tag.log 2>&1 || { tail -5 gpurun_out/l2_$tag.log; exit 1; }
+timeout -k 10 ${PMC_TIMEOUT:-150} rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCP_TCC_READ_REQ_sum --output-format csv -d gpurun_out/l2_$tag -- python3 tools/prof_case.py 4096 1080 fast 500 > gpurun_out/l2_$tag.log 2>&1 || { tail -5 gpurun_out/l2_$tag.log; exit 1; }
 python3 - <<PY
 import csv,glob
 f=glob.glob("gpurun_out/l2_$tag/**/*counter_collection.csv",recursive=True)[0]

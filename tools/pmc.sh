@@ -5,7 +5,7 @@ cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp
 tag=$1; shift
 ctrs=(); while [ "$1" != "--" ]; do ctrs+=("$1"); shift; done; shift
 rm -rf gpurun_out/pmc_$tag
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc "${ctrs[@]}" --output-format csv -d gpurun_out/pmc_$tag -- python3 tools/prof_case.py "$@" > gpurun_out/pmc_$tag.log 2>&1
+timeout -k 10 ${PMC_TIMEOUT:-150} rocprofv3 --kernel-trace --pmc "${ctrs[@]}" --output-format csv -d gpurun_out/pmc_$tag -- python3 tools/prof_case.py "$@" > gpurun_out/pmc_$tag.log 2>&1
 echo "pmc $tag rc=$?"
 python3 - <<PY
 import csv,glob,collections

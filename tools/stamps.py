@@ -16,3 +16,5 @@ s = list(buf)
 nw, n0 = max(s[5], 1), max(s[7], 1)
 print(f"{policy} {envs}x{cars}: {ms * 1e3 / 300:.2f} us/step; shader clocks per wave-step: driver (summed over driver waves / all waves) {s[0] / nw:.0f}, "
       f"sweep {s[3] / nw:.0f}, barrier wait {s[4] / nw:.0f}, whole step {s[6] / nw:.0f}; dynamics (per call) {s[2] / n0:.0f}")
+print(f"  inside the sweep, per wave-step: {s[9] / nw:.1f} rounds, store + hand-out + init {s[8] / nw:.0f} clocks ({s[8] / max(s[9], 1):.0f} per round), "
+      f"march {s[10] / nw:.0f} clocks over {s[11] / nw:.1f} iterations ({s[10] / max(s[11], 1):.0f} per iteration)")

@@ -91,6 +91,11 @@ int main(int argc, char** argv)
                             const float du = dxw * isx, dv = -(dyw * isy);
                             ftgp_ray_init(l.r, fmaf(du, -r0, u0), fmaf(dv, -r0, v0), du, dv, fabsf(1.0f / du), fabsf(1.0f / dv), W, H, fstride, plane256);
                             l.done = false;
+                            if (getenv("PRESTEP")) {          // what-if: the start cell's entry is at hand (no wave-iteration for it)
+                                const uint32_t wq = field[ftgp_ray_offset(l.r) >> 1];
+                                FtgpStep st; const bool near = ftgp_ray_step(l.r, wq, eps, st);
+                                ftgp_ray_commit(l.r, st, near ? ftgp_ray_fix(l.r, st) : st.t);
+                            }
                         }
                     }
                     empty[w] = base + nfree >= total;

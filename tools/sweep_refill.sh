@@ -3,7 +3,7 @@
 set -e
 cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out
 for n in "$@"; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math -w -mllvm -amdgpu-atomic-optimizer-strategy=None -DFTGP_REFILL=${n%%:*} -DFTGP_SLOTS=${n##*:} -o gpurun_out/libftgp_refill${n%%:*}_${n##*:}.so ft_grandprix_amd/csrc/ftgp_api.hip -ldl
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math -w -mllvm -amdgpu-atomic-optimizer-strategy=None -fno-slp-vectorize -DFTGP_REFILL=${n%%:*} -DFTGP_SLOTS=${n##*:} -o gpurun_out/libftgp_refill${n%%:*}_${n##*:}.so ft_grandprix_amd/csrc/ftgp_api.hip -ldl
 done
 python3 - "$@" <<'PY'
 import os, sys
