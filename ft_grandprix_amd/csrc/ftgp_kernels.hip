@@ -744,14 +744,29 @@ __device__ __forceinline__ void policy_disparity(const DeviceParams& P, float* _
     // keeps its flags as bits of mymask; launch_steps() guarantees m <= 64 * 64, i.e. chunk <= 64
     const int chunk = (m + FTGP_WAVE - 1) / FTGP_WAVE;
     const int first = lane * chunk, end = min(m, first + chunk);
+    // The reference compares |cur - prev| in binary64 with 0.6 (nidc.py:33).  In binary32, with T the float next above 0.6
+    // (the nearest one): rounding is monotone, so |fl(cur - prev)| > T implies the exact difference is > 0.6 and < T implies it
+    // is not; only a difference that rounds to exactly T needs the binary64 comparison (NaNs fail every test, as there).
     uint64_t mymask = 0;
     {
+        const float T = 0.60000002384185791015625f;
+        uint64_t unsure = 0;
         float prev = (first >= 1 && first < m) ? proc[first - 1] : 0.0f;
         for (int i = first; i < end; ++i) {
             const float cur = proc[i];
-            const bool flag = (i >= 1) && fabs((double)cur - (double)prev) > 0.6;
-            mymask |= (uint64_t)flag << (i - first);
+            const float ad = fabsf(cur - prev);
+            mymask |= (uint64_t)((i >= 1) && ad > T) << (i - first);
+            unsure |= (uint64_t)((i >= 1) && ad == T) << (i - first);
             prev = cur;
+        }
+        if (__any(unsure != 0)) {
+            uint64_t mk = unsure;
+            while (mk) {
+                const int bit = __builtin_ctzll(mk);
+                mk &= mk - 1;
+                const int i = first + bit;
+                if (fabs((double)proc[i] - (double)proc[i - 1]) > 0.6) mymask |= 1ull << bit;
+            }
         }
     }
     const int cnt = __popcll(mymask);

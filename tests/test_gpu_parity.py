@@ -167,6 +167,38 @@ def test_g1_device_policies_match_reference_drivers(product, R):
         np.testing.assert_array_equal(g.policy_eval("lobotomy", scans), 0.0)
 
 
+def test_disparity_threshold_edge_cases(product, oracle):
+    """K5 decides |cur - prev| > 0.6 in binary32 and falls back to the reference's binary64 comparison only when the binary32
+    difference rounds to the float next to 0.6: scans full of such pairs (both outcomes) against the oracle."""
+    T = np.float32(0.60000002384185791015625)
+    rng = np.random.default_rng(5)
+    pairs = {True: [], False: []}
+    while min(len(v) for v in pairs.values()) < 40:
+        prev = np.float32(rng.uniform(0.01, 3.0))
+        for k in range(-4, 5):
+            cur = np.float32(prev + np.float32(0.6))
+            for _ in range(abs(k)):
+                cur = np.nextafter(cur, np.float32(np.inf if k > 0 else -np.inf))
+            if np.float32(abs(np.float32(cur - prev))) == T:
+                pairs[bool(abs(float(cur) - float(prev)) > 0.6)].append((prev, cur))
+    assert all(len(v) >= 40 for v in pairs.values())
+    R = 90
+    eighth = R // 8
+    scans = np.full((80, R), 2.5, dtype=np.float32)
+    for row in range(80):
+        prev, cur = pairs[row % 2 == 0][row // 2]
+        at = eighth + 5 + (row * 7) % (R - 2 * eighth - 12)
+        lo, hi = (prev, cur) if row % 4 < 2 else (cur, prev)
+        scans[row, :at] = lo
+        scans[row, at:] = hi
+        scans[row, (at + 20) % R] = np.float32(9.0)            # somewhere to steer to
+    t = load_track("small-circle")
+    with capi.Env(product, t, n_envs=len(scans), n_rays=R) as g, capi.Env(oracle, t, n_envs=len(scans), n_rays=R) as o:
+        for name in ("nidc", "fast"):
+            np.testing.assert_array_equal(g.policy_eval(name, scans), o.policy_eval(name, scans))
+        assert len(np.unique(g.policy_eval("nidc", scans)[:, 1])) > 4
+
+
 @pytest.mark.parametrize("trace", ["forward", "reverse_start", "back_and_forth", "fast_jumps"])
 def test_g5_progress_block_on_gpu(product, trace):
     """K3 against the reference's progress block executed verbatim (fixture g5_progress.npz)."""
