@@ -210,7 +210,9 @@ def main():
                 "traffic": None, "kernel": env.kernel_name(), "kernel_ms_per_launch": kernel_s * 1e3,
                 "algorithmic_bytes_per_launch": bytes_per_launch, "frac_of_measured_copy_6290": achieved / HBM_MEASURED_COPY_GBS,
                 "rays_per_s": args.envs_per_gpu * args.cars * args.rays * args.steps / kernel_s,
-                "limiter": "valu-issue (see `valu`): the path sits above the HBM ridge, SURVEY.md 7.5"}
+                "limiter": "per-wave dependency chains (field load -> ~26 vector instructions -> next load) at 8 waves/SIMD: vector issue ~0.5 of "
+                           "the SIMD-32 peak (see `valu`), texture addresser ~0.5 busy, waves parked ~0.5 of the time (profiles/round2); "
+                           "far above the HBM ridge, SURVEY.md 7.5"}
         tr = committed_counters("traffic_latest.json", args.envs_per_gpu, args.rays, args.cars, args.policy)
         if tr is not None:
             # HBM bytes per launch = the committed PMC figure per env-step (FETCH_SIZE x2 + WRITE_SIZE, separate passes) scaled to this launch

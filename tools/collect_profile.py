@@ -55,16 +55,7 @@ os.makedirs(OUT, exist_ok=True)
 base = {"config": f"{ENVS} envs x {RAYS} rays, {POLICY}, {STEPS} steps per launch", "steps": STEPS, "n_envs": ENVS, "n_rays": RAYS, "cars": CARS,
         "policy": POLICY, "kernel_source_sha": sha()}
 
-# 1. the bench line + kernel stats of the same command
-run(["python3", "bench.py", "--steps", str(STEPS), "--warmup", "50"], f"{OUT}/bench.log", 600)
-line = [l for l in open(f"{OUT}/bench.log").read().splitlines() if l.startswith("{")][-1]
-open(f"{OUT}/bench.json", "w").write(line + "\n")
-shutil.rmtree(f"{OUT}/raw_stats", ignore_errors=True)
-run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", f"{OUT}/raw_stats", "--",
-     "python3", "bench.py", "--steps", str(STEPS), "--warmup", "50", "--no-cpu-baseline"], f"{OUT}/raw_stats.log", 600)
-shutil.copy(glob.glob(f"{OUT}/raw_stats/**/*kernel_stats.csv", recursive=True)[0], f"{OUT}/kernel_stats.csv")
-
-# 2. SQ counters (8 slots per pass)
+# 1. SQ counters (8 slots per pass)
 sq = dict(base, counters={})
 for tag, ctrs in (("a", ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_SALU", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY"]),
                   ("b", ["SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SMEM", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_SCA", "SQ_THREAD_CYCLES_VALU", "SQ_WAVES"]),
@@ -80,7 +71,7 @@ sq["derived"] = {"valu_insts_per_car_step": c["SQ_INSTS_VALU"] / n, "salu_insts_
                  "shader_clock_ghz": c["GRBM_GUI_ACTIVE"] / 8.0 / (sq["kernel_ms"] * 1e6)}
 json.dump(sq, open(f"{OUT}/sq_latest.json", "w"), indent=1)
 
-# 3. HBM traffic (separate passes; FETCH_SIZE costs 3 TCC slots, WRITE_SIZE 2)
+# 2. HBM traffic (separate passes; FETCH_SIZE costs 3 TCC slots, WRITE_SIZE 2)
 tr = dict(base)
 for name in ("FETCH_SIZE", "WRITE_SIZE"):
     c, meta = pmc(name, [name])
@@ -91,6 +82,21 @@ tr["traffic_bytes_per_launch"] = tr["write_bytes_per_launch"] + tr["fetch_bytes_
 tr["traffic_bytes_per_env_step"] = tr["traffic_bytes_per_launch"] / (ENVS * STEPS)
 tr["write_bytes_per_env_step"] = tr["write_bytes_per_launch"] / (ENVS * STEPS)
 json.dump(tr, open(f"{OUT}/traffic_latest.json", "w"), indent=1)
+
+# 3. the bench line reads these two files: give it the ones of this very visit (same sources, so nothing is "stale")
+PROFILES = "profiles/round2"
+for name in ("sq_latest.json", "traffic_latest.json"):
+    shutil.copy(f"{OUT}/{name}", f"{PROFILES}/{name}")
+
+# 4. the bench line + kernel stats of the same command
+run(["python3", "bench.py", "--steps", str(STEPS), "--warmup", "50"], f"{OUT}/bench.log", 600)
+line = [l for l in open(f"{OUT}/bench.log").read().splitlines() if l.startswith("{")][-1]
+open(f"{OUT}/bench.json", "w").write(line + "\n")
+shutil.rmtree(f"{OUT}/raw_stats", ignore_errors=True)
+run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", f"{OUT}/raw_stats", "--",
+     "python3", "bench.py", "--steps", str(STEPS), "--warmup", "50", "--no-cpu-baseline"], f"{OUT}/raw_stats.log", 600)
+shutil.copy(glob.glob(f"{OUT}/raw_stats/**/*kernel_stats.csv", recursive=True)[0], f"{OUT}/kernel_stats.csv")
+
 for d in glob.glob(f"{OUT}/raw_*"):
     if os.path.isdir(d):
         shutil.rmtree(d)
