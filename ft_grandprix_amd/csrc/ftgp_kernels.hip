@@ -142,8 +142,8 @@ __device__ __forceinline__ float ray_vs_car(const FtgpVehicle& v, const LidarFra
 // finished ray idles on its terminal cell, so the loop body has no active-lane predication); as soon as FTGP_REFILL lanes
 // of the wave are finished, their ranges are stored and they take the next rays of the pool together (one LDS atomic
 // per refill, rank among the free lanes via ballot/popcount).  Which lane marches which ray has no influence on any result.
-#ifndef FTGP_MASK_IDLE_LOADS
-#define FTGP_MASK_IDLE_LOADS 1
+#ifndef FTGP_PAD_ASM
+#define FTGP_PAD_ASM "v_add_u32 %0, %0, %3"
 #endif
 #ifndef FTGP_REFILL
 #define FTGP_REFILL (MULTI ? 56 : 48)     // measured optimum (tools/ab.sh): the multi-car refill also runs the inter-vehicle tests
@@ -286,12 +286,18 @@ __device__ __forceinline__ void lidar_pool(const DeviceParams& P, const Lds& L, 
         uint32_t w = FTGP_FIELD_OUT;
         bool alive = cj >= 0;            // lanes whose ray is known to sit on its terminal cell keep that cell's entry and issue no load
         for (int guard = 0; guard < 4 * 8192; ++guard) {
-            // the entry, zero-extended by the load itself; the wait belongs to it, everything below depends on w
-#if FTGP_MASK_IDLE_LOADS
-            if (alive)
-                asm volatile("global_load_ushort %0, %1, %2\n\ts_waitcnt vmcnt(0)" : "+v"(w) : "v"(ftgp_ray_offset(ray)), "s"(field));
-#else
-            asm volatile("global_load_ushort %0, %1, %2\n\ts_waitcnt vmcnt(0)" : "=v"(w) : "v"(ftgp_ray_offset(ray)), "s"(field));
+            // a finished ray idles on its terminal cell: it issues no load (w keeps that cell's entry) and the selects of
+            // ftgp_ray_commit() hold it there.  (Running the whole body under the mask of the unfinished lanes instead saves
+            // those selects and was measured 4 % slower: the divergent control flow costs more than three instructions.)
+            if (alive) asm volatile("global_load_ushort %0, %1, %2\n\ts_waitcnt vmcnt(0)" : "+v"(w) : "v"(ftgp_ray_offset(ray)), "s"(field));
+#ifdef FTGP_PAD_VALU        // diagnostic (tools/valu_cost.sh): FTGP_PAD_VALU independent filler instructions per march iteration; what one more costs
+            {   int pad0 = lane, pad1 = lane + 1; unsigned long long padm; double padd0 = 1.0, padd1 = 2.0;
+                #pragma unroll
+                for (int q = 0; q < FTGP_PAD_VALU / 2; ++q) {      // %0 scratch VGPR, %1 SGPR pair (write-only), %2 scratch VGPR pair, %3 lane index, %4 SGPR mask
+                    asm volatile(FTGP_PAD_ASM : "+v"(pad0), "=s"(padm), "+v"(padd0) : "v"(lane), "s"(live_mask) : "vcc");
+                    asm volatile(FTGP_PAD_ASM : "+v"(pad1), "=s"(padm), "+v"(padd1) : "v"(lane), "s"(live_mask) : "vcc");
+                }
+            }
 #endif
             FtgpStep st;
             const bool near = ftgp_ray_step(ray, w, eps, st);

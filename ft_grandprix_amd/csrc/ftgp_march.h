@@ -166,16 +166,20 @@ FTGP_HD int ftgp_ray_offset(const FtgpRay& r)
 #endif
 }
 
-struct FtgpStep { float sn; int t, cur, hi, xe, ye; bool stepx, live; };       // live: the ray is not on its terminal cell yet
+struct FtgpStep { float sn; int t, xe, ye; bool stepx, live; };       // live: the ray is not on its terminal cell yet
 
 // One generic iteration, first half: w is the field entry of the ray's cell.  Jumps to the far edge of the box
 // (s = min(sX, sY) of its exit boundaries) and estimates the transverse cell as floor(p + d * s).  Returns true when the
 // landing point is within `eps` of a pixel boundary: the caller then runs ftgp_ray_fix() before ftgp_ray_commit().
-FTGP_HD bool ftgp_ray_step(FtgpRay& r, uint32_t w, float eps, FtgpStep& st)
+// Otherwise the estimate needs no clamp: the ray leaves the box through the edge it reaches first, i.e. at a transverse
+// coordinate inside the box's span, and the estimate is off by far less than eps.
+// Vector instructions are chosen by what they cost on gfx950 (tools/valu_cost.sh): add / logic / shift / mov and binary32
+// add / mul / fma issue in 2 cycles per wave, everything else used here (selects, compares, conversions, 24-bit multiplies,
+// three-operand integer forms, fract) in 4.
+FTGP_HD bool ftgp_ray_step(const FtgpRay& r, uint32_t w, float eps, FtgpStep& st)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    // same arithmetic, spelled with the gfx9 forms the compiler does not pick by itself: byte operands straight out of the
-    // entry (SDWA), floor-and-convert in one instruction, hardware fract, three-operand median for the clamp
+    // byte operands straight out of the entry (SDWA), floor-and-convert in one instruction, hardware fract
     asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(st.xe) : "v"(r.ix), "v"(w));
     asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(st.ye) : "v"(r.iy), "v"(w));
     st.live = st.xe != r.ix;                                  // kx == 0: wall or ring cell
@@ -193,38 +197,37 @@ FTGP_HD bool ftgp_ray_step(FtgpRay& r, uint32_t w, float eps, FtgpStep& st)
     // also built with -fno-slp-vectorize for that reason)
     const float vX = fmaf(r.dvm, sX, r.pvm), vY = fmaf(r.dum, sY, r.pum);
     const float v = st.stepx ? vX : vY;
-    st.cur = st.stepx ? r.iy : r.ix; st.hi = (st.stepx ? st.ye : st.xe) - 1;
 #if defined(__HIP_DEVICE_COMPILE__)
-    int t;
-    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(t) : "v"(v));
-    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(st.t) : "v"(t), "v"(st.cur), "v"(st.hi));       // clamp: cur <= hi always
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(st.t) : "v"(v));
     const float frac = __builtin_amdgcn_fractf(v);            // v - floor(v), kept below 1: only ever compared with eps and 1 - eps
 #else
     const float fl = floorf(v);
-    int t = (int)fl;
-    t = t < st.cur ? st.cur : t; t = t > st.hi ? st.hi : t;
-    st.t = t;
+    st.t = (int)fl;
     const float frac = v - fl;
 #endif
     return st.live & (fabsf(frac - 0.5f) > 0.5f - eps);    // within eps of a boundary (and never for a NaN)
 }
 
-// the specification's comparisons for a landing point close to a boundary (sY(b) <= s after an x-jump, sX(b) < s after a y-jump)
+// the specification's comparisons for a landing point close to a boundary (sY(b) <= s after an x-jump, sX(b) < s after a y-jump),
+// inside the transverse span [cur, hi] of the box
 FTGP_HD int ftgp_ray_fix(const FtgpRay& r, const FtgpStep& st)
 {
     const float tp = st.stepx ? r.pvm : r.pum, tinv = st.stepx ? r.ivy : r.ivx;
-    const int t = st.t;
+    const int cur = st.stepx ? r.iy : r.ix, hi = (st.stepx ? st.ye : st.xe) - 1;
+    int t = st.t;
+    t = t < cur ? cur : t; t = t > hi ? hi : t;
     const float Sa = ((float)t - tp) * tinv, Sb = ((float)(t + 1) - tp) * tinv;
     const bool ca = st.stepx ? (Sa <= st.sn) : (Sa < st.sn), cb = st.stepx ? (Sb <= st.sn) : (Sb < st.sn);
-    const bool dec = (t > st.cur) & !ca;
-    const bool inc = !dec & (t < st.hi) & cb;
+    const bool dec = (t > cur) & !ca;
+    const bool inc = !dec & (t < hi) & cb;
     return t + (inc ? 1 : 0) - (dec ? 1 : 0);
 }
 
+// Second half.  A finished ray stays on its terminal cell and keeps the crossing time into it.
 FTGP_HD void ftgp_ray_commit(FtgpRay& r, const FtgpStep& st, int t)
 {
     const int nix = st.stepx ? st.xe : t, niy = st.stepx ? t : st.ye;
-    r.ix = st.live ? nix : r.ix; r.iy = st.live ? niy : r.iy;     // a finished ray stays on its terminal cell
+    r.ix = st.live ? nix : r.ix; r.iy = st.live ? niy : r.iy;
     r.s = st.live ? st.sn : r.s;
 }
 

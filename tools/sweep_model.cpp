@@ -107,6 +107,7 @@ int main(int argc, char** argv)
                     bool anynear = false; int ndone = 0;
                     std::vector<int> lineset;
                     for (auto& l : L) {
+                        if (l.done) { ++ndone; continue; }          // a finished ray is not stepped any more (lidar_pool: `alive`)
                         const int off = ftgp_ray_offset(l.r);
                         lineset.push_back(off >> 7);
                         const uint32_t wq = field[off >> 1];
