@@ -151,18 +151,25 @@ __device__ __forceinline__ float ray_vs_car(const FtgpVehicle& v, const LidarFra
 // number of set bits of `mask` below this lane
 __device__ __forceinline__ int rank_below(uint64_t mask) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0)); }
 
-// |1 / x| correctly rounded, as the specification's IEEE division gives it.  One Newton step on v_rcp_f32 (1 ulp) with
-// fused residuals is correctly rounded for every binary32 input of normal magnitude (checked exhaustively over all 2^32
-// bit patterns by ftgp_selftest / tests/test_gpu_parity.py); zeros, denormals and huge values take the division.
-__device__ __forceinline__ float rcp_abs(float x)
+// |1 / x| and |1 / y| correctly rounded, as the specification's IEEE divisions give them.  One Newton step on v_rcp_f32
+// (1 ulp) with fused residuals is correctly rounded for every binary32 input with 2^-100 < |x| < 2^100 (checked exhaustively
+// over all 2^32 bit patterns by ftgp_selftest / tests/test_gpu_parity.py); zeros, denormals, huge values and NaNs take the
+// division.  The range test is done on the bit patterns of both operands at once: b - (lo + 1) is below hi - lo - 1 (unsigned)
+// exactly for lo < b < hi, and the OR of two such differences can only be below that if both are -- an OR that is not sends
+// the wave through the per-lane test and the division, which is then simply not needed.
+__device__ __forceinline__ void rcp_abs2(float x, float y, float& rx, float& ry)
 {
-    const float ax = fabsf(x);
-    float y = __builtin_amdgcn_rcpf(ax);
-    const float e = fmaf(-ax, y, 1.0f);
-    y = fmaf(y, e, y);
-    const bool odd = !(ax > 0x1p-100f && ax < 0x1p100f);      // also true for a NaN
-    if (__any(odd)) { const float z = fabsf(1.0f / x); y = odd ? z : y; }
-    return y;
+    const float ax = fabsf(x), ay = fabsf(y);
+    float p = __builtin_amdgcn_rcpf(ax), q = __builtin_amdgcn_rcpf(ay);
+    const float ep = fmaf(-ax, p, 1.0f), eq = fmaf(-ay, q, 1.0f);
+    p = fmaf(p, ep, p); q = fmaf(q, eq, q);
+    const uint32_t lo1 = 0x0D800001u, span = 0x71800000u - 0x0D800001u;             // bit patterns of 2^-100 (+ 1) and 2^100
+    if (__any(((__float_as_uint(ax) - lo1) | (__float_as_uint(ay) - lo1)) >= span)) {
+        const bool oddx = !(ax > 0x1p-100f && ax < 0x1p100f), oddy = !(ay > 0x1p-100f && ay < 0x1p100f);      // also true for a NaN
+        const float zx = fabsf(1.0f / x), zy = fabsf(1.0f / y);
+        p = oddx ? zx : p; q = oddy ? zy : q;
+    }
+    rx = p; ry = q;
 }
 
 // diagnostic build only (tools/stamps.sh): per-phase shader-clock totals over all workgroups and steps; never in the product
@@ -271,7 +278,9 @@ __device__ __forceinline__ void lidar_pool(const DeviceParams& P, const Lds& L, 
                 const float dv = -(dyw * isy);
                 const float pu = fmaf(du, -r0, f4.x);
                 const float pv = fmaf(dv, -r0, f4.y);
-                ftgp_ray_init(ray, pu, pv, du, dv, rcp_abs(du), rcp_abs(dv), W, H, fstride, plane256);
+                float ivx, ivy;
+                rcp_abs2(du, dv, ivx, ivy);
+                ftgp_ray_init(ray, pu, pv, du, dv, ivx, ivy, W, H, fstride, plane256);
                 // a finished car's rangefinders are switched off (custom.py:1436-1439): its frame carries u0 = -inf, so the ray is
                 // parked like any ray that starts off the image, and reads 0 instead of -1
                 ray.result = (f4.x == -INFINITY) ? 0.0f : -1.0f;
@@ -336,7 +345,7 @@ __device__ __forceinline__ void window_flush(const DeviceParams& P, const float*
     }
 }
 
-// device arithmetic the kernels rely on, checked over every binary32 bit pattern: rcp_abs(x) == |1 / x| (IEEE division)
+// device arithmetic the kernels rely on, checked over every binary32 bit pattern: rcp_abs2() == |1 / x| (IEEE division) in either slot
 __global__ void ftgp_selftest_rcp_kernel(unsigned long long* __restrict__ mismatches)
 {
     unsigned long long bad = 0;
@@ -344,8 +353,12 @@ __global__ void ftgp_selftest_rcp_kernel(unsigned long long* __restrict__ mismat
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     for (uint32_t k = 0; k < per; ++k) {
         const float x = __uint_as_float(t * per + k);
-        const float a = rcp_abs(x), b = fabsf(1.0f / x);
-        const bool same = __float_as_uint(a) == __float_as_uint(b) || (a != a && b != b);
+        float a, a2;
+        rcp_abs2(x, 3.0f, a, a2);
+        const float b = fabsf(1.0f / x);
+        float c, c2;
+        rcp_abs2(0.7f, x, c2, c);                              // second operand too (and the first in range: the slow path only if x needs it)
+        const bool same = (__float_as_uint(a) == __float_as_uint(b) || (a != a && b != b)) && (__float_as_uint(c) == __float_as_uint(b) || (c != c && b != b));
         bad += same ? 0 : 1;
     }
     if (bad) atomicAdd(mismatches, bad);

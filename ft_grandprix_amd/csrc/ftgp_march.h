@@ -20,11 +20,20 @@
 #pragma once
 #include <math.h>
 #include <stdint.h>
+#include <string.h>
 
 #if defined(__HIPCC__) || defined(__CUDACC__)
 #define FTGP_HD __host__ __device__ __forceinline__
 #else
 #define FTGP_HD static inline
+#endif
+
+#if defined(__HIP_DEVICE_COMPILE__)
+FTGP_HD uint32_t ftgp_bits(float x) { return __float_as_uint(x); }
+FTGP_HD float ftgp_float(uint32_t b) { return __uint_as_float(b); }
+#else
+FTGP_HD uint32_t ftgp_bits(float x) { uint32_t b; memcpy(&b, &x, 4); return b; }
+FTGP_HD float ftgp_float(uint32_t b) { float x; memcpy(&x, &b, 4); return x; }
 #endif
 
 #define FTGP_FIELD_OUT 0x0100u
@@ -105,7 +114,7 @@ struct FtgpRay {
     int offC, ax, ay;
 };
 
-// A ray that marches nothing: it sits on ring cell (0, 0) of plane 0, which terminates at once and leaves `result` alone.
+// A ray that marches nothing: every cell of it maps to ring cell (0, 0) of plane 0, which terminates at once and leaves `result` alone.
 FTGP_HD void ftgp_ray_park(FtgpRay& r, float result)
 {
     r.pum = r.pvm = r.dum = r.dvm = r.ivx = r.ivy = 0.0f;
@@ -127,31 +136,38 @@ FTGP_HD void ftgp_ray_init(FtgpRay& r, float pu, float pv, float du, float dv, f
     const bool inside = fx >= 0.0f && fx < (float)W && fy >= 0.0f && fy < (float)H;
     const int ix0 = (int)fx, iy0 = (int)fy;
 #endif
-    const bool mx = du < 0.0f, my = dv < 0.0f;
+    // Mirrors, slope slice and offsets come out of sign bits with adds, shifts and logic (2-cycle instructions on gfx950)
+    // rather than compares and selects (4 each).  A direction component of -0 mirrors its axis too: harmless, the ray never
+    // steps along it.
+    const uint32_t bu = ftgp_bits(du), bv = ftgp_bits(dv);
+    const int mxm = (int)bu >> 31, mym = (int)bv >> 31;       // 0 / -1
     const float adu = fabsf(du), adv = fabsf(dv);
     const bool ydom = !(adu >= adv);
-    r.pum = mx ? -pu : pu; r.pvm = my ? -pv : pv;
+    r.pum = ftgp_float(ftgp_bits(pu) ^ (bu & 0x80000000u));   // mirrored ? -p : p
+    r.pvm = ftgp_float(ftgp_bits(pv) ^ (bv & 0x80000000u));
     r.dum = adu; r.dvm = adv;
     r.ivx = ivx; r.ivy = ivy;
     r.s = 0.0f; r.result = -1.0f;
-    uint32_t sector = (mx ? 1u : 0u) | (my ? 2u : 0u) | (ydom ? 4u : 0u);
-    {   // slope slice: the number of k in 1 .. NS - 1 with NS * minor > k * major (exact in binary32 for NS <= 4)
+    uint32_t sector = ((uint32_t)mxm & 1u) | ((uint32_t)mym & 2u) | (ydom ? 4u : 0u);
+    {   // slope slice: the number of k in 1 .. NS - 1 with NS * minor > k * major; "a > b" as the sign of the rounded b - a
+        // (a rounded difference has the sign of the exact one, and equal operands give +0)
         const float mn = ydom ? adu : adv, mj = ydom ? adv : adu;
-        if (FTGP_SLOPE_SLICES == 2) sector |= (2.0f * mn > mj) ? 8u : 0u;
-        if (FTGP_SLOPE_SLICES == 4) sector |= ((4.0f * mn > mj ? 1u : 0u) + (2.0f * mn > mj ? 1u : 0u) + (4.0f * mn > 3.0f * mj ? 1u : 0u)) << 3;
+        if (FTGP_SLOPE_SLICES == 2) sector |= (ftgp_bits(fmaf(-2.0f, mn, mj)) >> 31) << 3;
+        if (FTGP_SLOPE_SLICES == 4)
+            sector |= ((ftgp_bits(fmaf(-4.0f, mn, mj)) >> 31) + (ftgp_bits(fmaf(-2.0f, mn, mj)) >> 31) + (ftgp_bits(fmaf(-4.0f, mn, 3.0f * mj)) >> 31)) << 3;
     }
-    const int mxm = mx ? -1 : 0, mym = my ? -1 : 0, F = 2 * fstride;
     r.ix = ix0 ^ mxm; r.iy = iy0 ^ mym;
-    r.ax = 2 + 4 * mxm; r.ay = (F ^ mym) - mym;               // +-2, +-F
-    // 2 * (x + 1) = ix * ax + (ax + 2) / 2 - ... : both complements cost half their stride, hence (ax + ay) / 2 (exact, both even)
+    const int hy = (fstride ^ mym) - mym;                     // +-fstride
+    r.ax = 2 + 4 * mxm; r.ay = hy + hy;                       // +-2, +-2 * fstride
+    // 2 * (x + 1) = ix * ax + (ax + 2) / 2 - ... : both complements cost half their stride, hence (ax + ay) / 2 = 1 + 2 * mxm + hy
 #if defined(__HIP_DEVICE_COMPILE__)
     uint32_t plane;                                           // plane256 < 2^24; spelled out, or the shift below is folded into a 32-bit multiply
     asm("v_mul_u32_u24 %0, %1, %2" : "=v"(plane) : "v"(sector), "s"(plane256));
 #else
     const uint32_t plane = sector * plane256;
 #endif
-    r.offC = (int)(plane << 8) + (fstride + 1) + ((r.ax + r.ay) >> 1);
-    if (!inside) { r.ix = r.iy = 0; r.offC = 0; r.ax = r.ay = 0; }       // starts off the image: ring cell (0, 0), result stays -1
+    r.offC = (int)(plane << 8) + (fstride + 2) + (mxm + mxm) + hy;
+    if (!inside) { r.offC = 0; r.ax = r.ay = 0; }             // starts off the image: every cell maps to ring cell (0, 0) of plane 0, result stays -1
 }
 
 FTGP_HD int ftgp_ray_offset(const FtgpRay& r)
