@@ -210,6 +210,7 @@ __device__ __forceinline__ void lidar_pool(const DeviceParams& P, const Lds& L, 
     bool done = true;                // the lane's ray sits on its terminal cell (or the lane has none)
     bool pool_empty = false;         // wave-uniform
     bool hit = false;                // ... and that cell is a wall (not the ring)
+    uint64_t live_mask = 0;          // lanes whose ray is still on its way (wave-uniform)
     for (int round = 0; round < (1 << 20); ++round) {
         STAMP(ta);
         // ---- finished rays: store the range ...
@@ -252,7 +253,7 @@ __device__ __forceinline__ void lidar_pool(const DeviceParams& P, const Lds& L, 
         }
         // ---- ... and take the next rays of the pool: the free lanes get consecutive pool indices base, base + 1, ...
         if (!pool_empty) {
-            const uint64_t free_mask = __ballot(done);
+            const uint64_t free_mask = ~live_mask;                   // wave-uniform: every lane of the wave is in here
             const int nfree = __popcll(free_mask);
             int base = 0;
             if (lane == 0) base = atomicAdd(pool, nfree);
@@ -262,9 +263,9 @@ __device__ __forceinline__ void lidar_pool(const DeviceParams& P, const Lds& L, 
             int c, j;
             if (R >= FTGP_WAVE) {
                 const int c0 = (int)__umulhi((uint32_t)base, magic), j0 = base - c0 * R;
-                j = j0 + rank;
-                const bool wrap = j >= R;
-                c = wrap ? c0 + 1 : c0; j = wrap ? j - R : j;
+                const int d = j0 + rank - R;                         // >= 0: the ray belongs to the next car
+                const int same = d >> 31;                            // -1 / 0 (adds and shifts: 2-cycle instructions; a compare and a select cost 4 each)
+                c = c0 + 1 + same; j = d + (R & same);
             } else {
                 c = (int)__umulhi((uint32_t)(base + rank), magic); j = base + rank - c * R;
             }
@@ -291,7 +292,6 @@ __device__ __forceinline__ void lidar_pool(const DeviceParams& P, const Lds& L, 
         STAMP(tb); STAMP_ADD(8, tb - ta); STAMP_ADD(9, 1);
         // ---- march until enough lanes are free to make a batched refill worthwhile (or, at the end, until all are done)
         const int want = pool_empty ? FTGP_WAVE : FTGP_REFILL;
-        uint64_t live_mask = 0;
         uint32_t w = FTGP_FIELD_OUT;
         bool alive = cj >= 0;            // lanes whose ray is known to sit on its terminal cell keep that cell's entry and issue no load
         for (int guard = 0; guard < 4 * 8192; ++guard) {
@@ -320,7 +320,7 @@ __device__ __forceinline__ void lidar_pool(const DeviceParams& P, const Lds& L, 
         }
         STAMP(tc); STAMP_ADD(10, tc - tb);
         // a finished ray has just looked its terminal cell up once more: w is that cell's entry
-        done = !((live_mask >> lane) & 1ull);
+        done = !alive;
         hit = w == 0u;
     }
 }
