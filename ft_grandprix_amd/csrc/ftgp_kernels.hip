@@ -726,6 +726,22 @@ __device__ __forceinline__ void dynamics_lanes(const DeviceParams& P, const Lds&
     if (on && r == 0) frame_write(P, v, st, next_frames + c);
 }
 
+// Inclusive prefix sum over the 64 lanes of a wave with data-parallel-primitive moves (no LDS round trips): three shifts
+// inside each row of 16 lanes, two more across its banks, then the row totals broadcast down (lane 15 of rows 0 and 2 into
+// rows 1 and 3, lane 31 into rows 2 and 3).  A lane that a step does not address adds 0.
+__device__ __forceinline__ int wave_inclusive_sum(int x)
+{
+    const int s1 = __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);      // row_shr:1
+    const int s2 = __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);      // row_shr:2
+    const int s3 = __builtin_amdgcn_update_dpp(0, x, 0x113, 0xf, 0xf, true);      // row_shr:3
+    int v = x + s1 + s2 + s3;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xe, true);                // row_shr:4, banks 1..3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xc, true);                // row_shr:8, banks 2..3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);                // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);                // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
 // =============================================================================================
 // K5: on-device drivers.  nidc.py:12-131 / fast.py:11-139 restated for one wave; the previous scan sits in LDS.
 // =============================================================================================
@@ -789,9 +805,7 @@ __device__ __forceinline__ void policy_disparity(const DeviceParams& P, float* _
         }
     }
     const int cnt = __popcll(mymask);
-    int incl = cnt;
-    #pragma unroll
-    for (int d = 1; d < FTGP_WAVE; d <<= 1) { const int t = __shfl_up(incl, d, FTGP_WAVE); if (lane >= d) incl += t; }
+    const int incl = wave_inclusive_sum(cnt);
     const int excl = incl - cnt;
     const int total = __builtin_amdgcn_readlane(incl, FTGP_WAVE - 1);
     for (int c0 = 0; c0 < total; c0 += FTGP_WAVE) {
