@@ -146,7 +146,7 @@ __device__ __forceinline__ float ray_vs_car(const FtgpVehicle& v, const LidarFra
 #define FTGP_PAD_ASM "v_add_u32 %0, %0, %3"
 #endif
 #ifndef FTGP_REFILL
-#define FTGP_REFILL (MULTI ? 56 : 48)     // measured optimum (tools/ab.sh): the multi-car refill also runs the inter-vehicle tests
+#define FTGP_REFILL (MULTI ? 60 : 48)     // measured optimum (tools/ab.sh): the multi-car refill also runs the inter-vehicle tests
 #endif
 // number of set bits of `mask` below this lane
 __device__ __forceinline__ int rank_below(uint64_t mask) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0)); }
