@@ -194,8 +194,8 @@ def main():
         metrics = gather()                       # the only collective; side stream
         kms = env.last_kernel_ms()               # HIP events on the launch stream; also synchronises
         best_ms = kms if best_ms is None else min(best_ms, kms)
+    wall = (time.perf_counter() - t0) / args.repeats     # this rank is done (the event wait above synchronised); the max over ranks follows
     barrier()
-    wall = (time.perf_counter() - t0) / args.repeats
     kernel_ms = kms if args.repeats == 1 else best_ms
     if rdzv is not None:
         wall, kernel_ms = [float(x) for x in rdzv.max([wall, kernel_ms])]     # max over ranks
