@@ -463,6 +463,33 @@ def test_adversarial_rays_through_pixel_corners(product, oracle):
         np.testing.assert_array_equal(g.lidar(), o.lidar())
 
 
+@pytest.mark.parametrize("name", ["track", "inkscape"])
+def test_lidar_from_anywhere_on_the_image(product, oracle, name):
+    """LiDAR centres anywhere on the image -- on walls, off the track, at the border, a few off the image -- and headings
+    that make direction components exactly zero: the GPU march against the plain-DDA specification, bit for bit."""
+    t = load_track(name)
+    n = 256
+    g, o = both(product, oracle, t, n_envs=n, n_rays=360, spawn_mode=1, seed=11)
+    with g, o:
+        oracle.dll.oracle_set_lidar_mode(o.h, 2)            # the specification itself (plain DDA)
+        pose = o.pose()
+        rng = np.random.default_rng(17)
+        w, h = t.width * t.px_size_x, t.height * t.px_size_y
+        u = rng.uniform(-0.02, 1.02, n); v = rng.uniform(-0.02, 1.02, n)
+        u[:16] = rng.choice([0.0, 1.0], 16) + rng.uniform(-1e-3, 1e-3, 16)         # hugging the left / right border
+        yaw = rng.uniform(-np.pi, np.pi, n)
+        yaw[16:48] = (np.pi / 2) * rng.integers(-2, 3, 32)                          # axis-aligned cars
+        pose[:, 0] = t.origin_x + u * w
+        pose[:, 1] = t.origin_y - v * h
+        pose[:, 3], pose[:, 6] = np.cos(yaw / 2), np.sin(yaw / 2)
+        pose[:, 7:] = 0
+        g.set_pose(pose); o.set_pose(pose)
+        g.step(1); o.step(1)
+        rg, ro = g.lidar(), o.lidar()
+        np.testing.assert_array_equal(rg, ro)
+        assert (rg == -1).any() and (rg == 0).any() and (rg > 1.0).any()           # off-image starts, starts on walls, long rays
+
+
 def test_finished_cars_become_ghosts(product, oracle):
     """custom.py:1367-1371,1441-1466: a car that reached lap_target gets the null driver, stops colliding and is invisible."""
     t = load_track("circle")
