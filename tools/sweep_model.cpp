@@ -61,6 +61,46 @@ int main(int argc, char** argv)
     for (int j = 0; j < R; ++j) { const double phi = ((360.0 / R) * j - 90.0) * (M_PI / 180.0); bx[j] = (float)sin(phi); by[j] = (float)(-cos(phi)); }
     const float isx = (float)(1.0 / ph[1]), isy = (float)(1.0 / ph[2]), r0 = 0.03f;
     long wave_iters = 0, refills = 0, fixes = 0, lane_iters = 0, rays = 0, max_wave_iters_sum = 0, lines = 0;
+    // what-if SORTED=1: the pool hands a car's rays out by descending iteration count (as known from this very pose: an upper
+    // bound for "sort by the previous step's counts"); SORTED=2: ascending
+    const int sorted_mode = getenv("SORTED") ? atoi(getenv("SORTED")) : 0;
+    std::vector<std::vector<int>> perm(n_cars);
+    if (sorted_mode) {
+        for (int c = 0; c < n_cars; ++c) {
+            std::vector<std::pair<int, int>> key(R);
+            const double* p = &pose[(size_t)c * 4];
+            const double ch = 1.0 - 2.0 * (p[3] * p[3]), sh = 2.0 * (p[2] * p[3]);
+            const double lcx = p[0] + (ch * -0.0525 - sh * 0.0), lcy = p[1] + (sh * -0.0525 + ch * 0.0);
+            const float u0 = (float)((lcx - ph[3]) * (1.0 / ph[1])), v0 = (float)((ph[4] - lcy) * (1.0 / ph[2]));
+            const float chf = (float)ch, shf = (float)sh;
+            for (int j = 0; j < R; ++j) {
+                const float dxw = fmaf(chf, bx[j], -(shf * by[j])), dyw = fmaf(shf, bx[j], chf * by[j]);
+                const float du = dxw * isx, dv = -(dyw * isy);
+                FtgpRay r; ftgp_ray_init(r, fmaf(du, -r0, u0), fmaf(dv, -r0, v0), du, dv, fabsf(1.0f / du), fabsf(1.0f / dv), W, H, fstride, plane256);
+                int n = 0;
+                for (; n < 100000; ++n) {
+                    const uint32_t wq = field[ftgp_ray_offset(r) >> 1];
+                    FtgpStep st; const bool near = ftgp_ray_step(r, wq, eps, st);
+                    ftgp_ray_commit(r, st, near ? ftgp_ray_fix(r, st) : st.t);
+                    if (!st.live) break;
+                }
+                // SORTED=1 by count (descending), 2 ascending, 3 by range (descending, quantised to 1/8 world unit)
+                const int rq = (int)(fabsf(r.s) * 8.0f);
+                key[j] = { sorted_mode == 1 ? -n : sorted_mode == 3 ? -rq : n, j };
+            }
+            perm[c].resize(R);
+            const int BS = getenv("BLOCK") ? atoi(getenv("BLOCK")) : 1;
+            if (BS > 1 && R % BS == 0) {          // blocks of BS consecutive rays ordered by their largest key (descending keys are negative: min)
+                std::vector<std::pair<int, int>> bk(R / BS);
+                for (int b = 0; b < R / BS; ++b) { int m = 1 << 30; for (int o = 0; o < BS; ++o) m = std::min(m, key[b * BS + o].first); bk[b] = { m, b }; }
+                std::stable_sort(bk.begin(), bk.end());
+                for (int k = 0; k < R / BS; ++k) for (int o = 0; o < BS; ++o) perm[c][k * BS + o] = bk[k].second * BS + o;
+            } else {
+                std::stable_sort(key.begin(), key.end());
+                for (int j = 0; j < R; ++j) perm[c][j] = key[j].second;
+            }
+        }
+    }
     struct Lane { FtgpRay r; int g; bool done; };
     for (int c0 = 0; c0 < n_cars; c0 += cpb) {
         const int nc = std::min(cpb, n_cars - c0), total = nc * R;
@@ -81,7 +121,7 @@ int main(int argc, char** argv)
                     for (auto& l : L) if (l.done) {
                         const int mine = base + rank++;
                         if (mine < total) {
-                            l.g = mine; const int c = mine / R, j = mine % R;
+                            l.g = mine; const int c = mine / R, j = sorted_mode ? perm[c0 + c][mine % R] : mine % R;
                             const double* p = &pose[(size_t)(c0 + c) * 4];
                             const double ch = 1.0 - 2.0 * (p[3] * p[3]), sh = 2.0 * (p[2] * p[3]);
                             const double lcx = p[0] + (ch * -0.0525 - sh * 0.0), lcy = p[1] + (sh * -0.0525 + ch * 0.0);
