@@ -76,6 +76,9 @@ struct FtgpEnv {
     CarState* d_cars = nullptr; float* d_ranges = nullptr; int64_t* d_steps = nullptr;
     uint8_t* d_env_mask = nullptr; uint8_t* d_car_mask = nullptr; double* d_ctrl = nullptr; double* d_pose = nullptr;
     double* d_metrics = nullptr; double* d_gather = nullptr;
+    double* h_metrics = nullptr;      // pinned landing buffer of the metrics record(s): the copy back is one small DMA, not a staged one
+    int h_metrics_ranks = 0;
+    double* h_metrics_dev = nullptr;  // the same buffer as the device sees it: a single-rank record is written straight into it
     int32_t* d_prog = nullptr; double* d_core = nullptr;
     std::vector<int32_t> h_prog; std::vector<double> h_core;
     bool rows_valid = false;          // h_prog / h_core mirror the device state (cleared by every call that changes it)
@@ -320,6 +323,7 @@ int ftgp_destroy(FtgpEnv* e)
     void* bufs[] = { e->d_field, e->d_bits, e->d_nearbits, e->d_cover, e->d_params, e->d_veh, e->d_path, e->d_spawn, e->d_ray, e->d_cars, e->d_ranges,
                      e->d_steps, e->d_env_mask, e->d_car_mask, e->d_ctrl, e->d_pose, e->d_metrics, e->d_gather, e->d_prog, e->d_core };
     for (void* b : bufs) if (b) (void)hipFree(b);
+    if (e->h_metrics) (void)hipHostFree(e->h_metrics);
     if (e->ev_start) (void)hipEventDestroy(e->ev_start);
     if (e->ev_stop) (void)hipEventDestroy(e->ev_stop);
     if (e->ev_metrics) (void)hipEventDestroy(e->ev_metrics);
@@ -515,6 +519,8 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
     CREATE_TRY(hipMalloc(&e->d_ctrl, sizeof(double) * 2 * n_cars));
     CREATE_TRY(hipMalloc(&e->d_pose, sizeof(double) * FTGP_POSE_DOUBLES * n_cars));
     CREATE_TRY(hipMalloc(&e->d_metrics, sizeof(double) * FTGP_METRIC_DOUBLES));
+    CREATE_TRY(hipHostMalloc(&e->h_metrics, sizeof(double) * FTGP_METRIC_DOUBLES, hipHostMallocMapped)); e->h_metrics_ranks = 1;
+    CREATE_TRY(hipHostGetDevicePointer((void**)&e->h_metrics_dev, e->h_metrics, 0));
     CREATE_TRY(hipMalloc(&e->d_prog, sizeof(int32_t) * FTGP_PROGRESS_INTS * n_cars));
     CREATE_TRY(hipMalloc(&e->d_core, sizeof(double) * kCoreDoubles * n_cars));
     CREATE_TRY(hipMemcpy(e->d_bits, tab.bits.data(), sz_bits, hipMemcpyHostToDevice));
@@ -717,15 +723,21 @@ int ftgp_get_steps(FtgpEnv* e, int64_t* out)
     return 0;
 }
 
+// the record of this GPU, reduced on the compute stream and written by the kernel straight into pinned host memory
+static int metrics_to_host(FtgpEnv* e, double* out)
+{
+    hipLaunchKernelGGL(ftgp_metrics_kernel, dim3(1), dim3(FTGP_METRIC_THREADS), 0, e->stream, e->P, e->h_metrics_dev);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    memcpy(out, e->h_metrics, sizeof(double) * FTGP_METRIC_DOUBLES);
+    return 0;
+}
+
 int ftgp_metrics_local(FtgpEnv* e, double* out)
 {
     if (!e || !out) return fail(FTGP_ERR_ARG, "null argument%s");
     HIP_TRY(hipSetDevice(e->device));
-    hipLaunchKernelGGL(ftgp_metrics_kernel, dim3(1), dim3(256), 0, e->stream, e->P, e->d_metrics);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(out, e->d_metrics, sizeof(double) * FTGP_METRIC_DOUBLES, hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
-    return 0;
+    return metrics_to_host(e, out);
 }
 
 int ftgp_comm_unique_id(uint8_t id_out[128])
@@ -749,6 +761,13 @@ int ftgp_comm_init(FtgpEnv* e, const uint8_t id[128], int rank, int world_size)
     if (r != 0) return fail(FTGP_ERR_COMM, "ncclCommInitRank: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
     e->rank = rank; e->world = world_size;
     HIP_TRY(hipMalloc(&e->d_gather, sizeof(double) * FTGP_METRIC_DOUBLES * (size_t)world_size));
+    if (world_size > e->h_metrics_ranks) {
+        if (e->h_metrics) (void)hipHostFree(e->h_metrics);
+        e->h_metrics = nullptr; e->h_metrics_ranks = 0;
+        HIP_TRY(hipHostMalloc(&e->h_metrics, sizeof(double) * FTGP_METRIC_DOUBLES * (size_t)world_size, hipHostMallocMapped));
+        HIP_TRY(hipHostGetDevicePointer((void**)&e->h_metrics_dev, e->h_metrics, 0));
+        e->h_metrics_ranks = world_size;
+    }
     return 0;
 }
 
@@ -757,19 +776,16 @@ int ftgp_metrics_allgather(FtgpEnv* e, double* out)
     if (!e || !out) return fail(FTGP_ERR_ARG, "null argument%s");
     HIP_TRY(hipSetDevice(e->device));
     // reduce on the compute stream (it reads the state the step kernel wrote), gather on the side stream
-    hipLaunchKernelGGL(ftgp_metrics_kernel, dim3(1), dim3(256), 0, e->stream, e->P, e->d_metrics);
+    if (!e->comm || e->world == 1) return metrics_to_host(e, out);
+    hipLaunchKernelGGL(ftgp_metrics_kernel, dim3(1), dim3(FTGP_METRIC_THREADS), 0, e->stream, e->P, e->d_metrics);
     HIP_TRY(hipGetLastError());
-    if (!e->comm || e->world == 1) {
-        HIP_TRY(hipMemcpyAsync(out, e->d_metrics, sizeof(double) * FTGP_METRIC_DOUBLES, hipMemcpyDeviceToHost, e->stream));
-        HIP_TRY(hipStreamSynchronize(e->stream));
-        return 0;
-    }
     HIP_TRY(hipEventRecord(e->ev_metrics, e->stream));
     HIP_TRY(hipStreamWaitEvent(e->side, e->ev_metrics, 0));
     int r = g_rccl.AllGather(e->d_metrics, e->d_gather, FTGP_METRIC_DOUBLES, kNcclFloat64, e->comm, e->side);
     if (r != 0) return fail(FTGP_ERR_COMM, "ncclAllGather: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
-    HIP_TRY(hipMemcpyAsync(out, e->d_gather, sizeof(double) * FTGP_METRIC_DOUBLES * (size_t)e->world, hipMemcpyDeviceToHost, e->side));
+    HIP_TRY(hipMemcpyAsync(e->h_metrics, e->d_gather, sizeof(double) * FTGP_METRIC_DOUBLES * (size_t)e->world, hipMemcpyDeviceToHost, e->side));
     HIP_TRY(hipStreamSynchronize(e->side));
+    memcpy(out, e->h_metrics, sizeof(double) * FTGP_METRIC_DOUBLES * (size_t)e->world);
     return 0;
 }
 

@@ -1197,11 +1197,13 @@ __global__ void ftgp_box_field_kernel(const uint16_t* __restrict__ runx, const u
     out[i] = (uint16_t)e;
 }
 
-// Metrics record (FTGP_METRIC_DOUBLES): one block, deterministic tree reduction (integers are exact in f64).
-__global__ void __launch_bounds__(256) ftgp_metrics_kernel(DeviceParams P, double* __restrict__ out)
+// Metrics record (FTGP_METRIC_DOUBLES): one block of 1024 threads (a handful of cars each: the records are 448 B apart, so the
+// loads want to be in flight together), tree reduction; the sums are integers, exact in binary64 in any order.
+#define FTGP_METRIC_THREADS 1024
+__global__ void __launch_bounds__(FTGP_METRIC_THREADS) ftgp_metrics_kernel(DeviceParams P, double* __restrict__ out)
 {
-    __shared__ double red[5][256];
-    __shared__ double rmin[256], rmax[256];
+    __shared__ double red[5][FTGP_METRIC_THREADS];
+    __shared__ double rmin[FTGP_METRIC_THREADS], rmax[FTGP_METRIC_THREADS];
     double steps = 0, laps = 0, absc = 0, fin = 0, off = 0, tmin = INFINITY, tmax = -INFINITY;
     for (int e = threadIdx.x; e < P.n_envs; e += blockDim.x) steps += (double)P.steps[e];
     for (int i = threadIdx.x; i < P.n_cars; i += blockDim.x) {
@@ -1214,7 +1216,7 @@ __global__ void __launch_bounds__(256) ftgp_metrics_kernel(DeviceParams P, doubl
     red[0][threadIdx.x] = steps; red[1][threadIdx.x] = laps; red[2][threadIdx.x] = absc;
     red[3][threadIdx.x] = fin; red[4][threadIdx.x] = off; rmin[threadIdx.x] = tmin; rmax[threadIdx.x] = tmax;
     __syncthreads();
-    for (int w = 128; w >= 1; w >>= 1) {
+    for (int w = FTGP_METRIC_THREADS / 2; w >= 1; w >>= 1) {
         if ((int)threadIdx.x < w) {
             for (int q = 0; q < 5; ++q) red[q][threadIdx.x] += red[q][threadIdx.x + w];
             rmin[threadIdx.x] = fmin(rmin[threadIdx.x], rmin[threadIdx.x + w]);
