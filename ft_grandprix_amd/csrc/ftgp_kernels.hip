@@ -1198,12 +1198,18 @@ __global__ void ftgp_box_field_kernel(const uint16_t* __restrict__ runx, const u
 }
 
 // Metrics record (FTGP_METRIC_DOUBLES): one block of 1024 threads (a handful of cars each: the records are 448 B apart, so the
-// loads want to be in flight together), tree reduction; the sums are integers, exact in binary64 in any order.
+// loads want to be in flight together); reduction inside each wave by shuffles, then across the 16 waves through LDS.  The
+// sums are integers, exact in binary64 in any order.
 #define FTGP_METRIC_THREADS 1024
+__device__ __forceinline__ double wave_sum_f64(double v)
+{
+    #pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_f64(v, m);
+    return v;
+}
 __global__ void __launch_bounds__(FTGP_METRIC_THREADS) ftgp_metrics_kernel(DeviceParams P, double* __restrict__ out)
 {
-    __shared__ double red[5][FTGP_METRIC_THREADS];
-    __shared__ double rmin[FTGP_METRIC_THREADS], rmax[FTGP_METRIC_THREADS];
+    __shared__ double part[7][FTGP_METRIC_THREADS / FTGP_WAVE];
     double steps = 0, laps = 0, absc = 0, fin = 0, off = 0, tmin = INFINITY, tmax = -INFINITY;
     for (int e = threadIdx.x; e < P.n_envs; e += blockDim.x) steps += (double)P.steps[e];
     for (int i = threadIdx.x; i < P.n_cars; i += blockDim.x) {
@@ -1213,19 +1219,19 @@ __global__ void __launch_bounds__(FTGP_METRIC_THREADS) ftgp_metrics_kernel(Devic
         const int n = a.n_times < FTGP_MAX_LAP_TIMES ? a.n_times : FTGP_MAX_LAP_TIMES;
         for (int k = 0; k < n; ++k) { tmin = fmin(tmin, a.times[k]); tmax = fmax(tmax, a.times[k]); }
     }
-    red[0][threadIdx.x] = steps; red[1][threadIdx.x] = laps; red[2][threadIdx.x] = absc;
-    red[3][threadIdx.x] = fin; red[4][threadIdx.x] = off; rmin[threadIdx.x] = tmin; rmax[threadIdx.x] = tmax;
+    const int lane = threadIdx.x & (FTGP_WAVE - 1), wave = threadIdx.x >> 6;
+    steps = wave_sum_f64(steps); laps = wave_sum_f64(laps); absc = wave_sum_f64(absc); fin = wave_sum_f64(fin); off = wave_sum_f64(off);
+    #pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { tmin = fmin(tmin, shfl_xor_f64(tmin, m)); tmax = fmax(tmax, shfl_xor_f64(tmax, m)); }
+    if (lane == 0) { part[0][wave] = steps; part[1][wave] = laps; part[2][wave] = absc; part[3][wave] = fin; part[4][wave] = off; part[5][wave] = tmin; part[6][wave] = tmax; }
     __syncthreads();
-    for (int w = FTGP_METRIC_THREADS / 2; w >= 1; w >>= 1) {
-        if ((int)threadIdx.x < w) {
-            for (int q = 0; q < 5; ++q) red[q][threadIdx.x] += red[q][threadIdx.x + w];
-            rmin[threadIdx.x] = fmin(rmin[threadIdx.x], rmin[threadIdx.x + w]);
-            rmax[threadIdx.x] = fmax(rmax[threadIdx.x], rmax[threadIdx.x + w]);
-        }
-        __syncthreads();
-    }
     if (threadIdx.x == 0) {
-        out[0] = red[0][0]; out[1] = (double)P.n_cars; out[2] = red[1][0]; out[3] = red[2][0];
-        out[4] = red[3][0]; out[5] = red[4][0]; out[6] = rmin[0]; out[7] = rmax[0];
+        double r[7] = { 0, 0, 0, 0, 0, INFINITY, -INFINITY };
+        for (int w = 0; w < FTGP_METRIC_THREADS / FTGP_WAVE; ++w) {
+            for (int q = 0; q < 5; ++q) r[q] += part[q][w];
+            r[5] = fmin(r[5], part[5][w]); r[6] = fmax(r[6], part[6][w]);
+        }
+        out[0] = r[0]; out[1] = (double)P.n_cars; out[2] = r[1]; out[3] = r[2];
+        out[4] = r[3]; out[5] = r[4]; out[6] = r[5]; out[7] = r[6];
     }
 }
