@@ -490,6 +490,23 @@ def test_lidar_from_anywhere_on_the_image(product, oracle, name):
         assert (rg == -1).any() and (rg == 0).any() and (rg > 1.0).any()           # off-image starts, starts on walls, long rays
 
 
+def test_large_image_4000x3000(product, oracle):
+    """A 4000 x 3000 synthetic oval (1 cm pixels: the LiDAR ring spans 6 pixels, eps = 2^-9): one sweep against the
+    plain-DDA specification and a closed loop against the oracle, bit for bit."""
+    from ft_grandprix_amd.track import synthetic_oval
+    t = synthetic_oval(width=4000, height=3000, half_width_px=70.0, wall_px=2.0)
+    g, o = both(product, oracle, t, n_envs=48, n_rays=360, spawn_mode=1, seed=4)
+    with g, o:
+        oracle.dll.oracle_set_lidar_mode(o.h, 2)            # the specification itself (plain DDA)
+        g.step(1); o.step(1)
+        rg = g.lidar()
+        np.testing.assert_array_equal(rg, o.lidar())
+        assert (rg > 0).mean() > 0.9 and rg.max() > 5.0
+        oracle.dll.oracle_set_lidar_mode(o.h, 0)
+        g.rollout("nidc", 150); o.rollout("nidc", 150)
+        assert_same_state(g, o)
+
+
 def test_finished_cars_become_ghosts(product, oracle):
     """custom.py:1367-1371,1441-1466: a car that reached lap_target gets the null driver, stops colliding and is invisible."""
     t = load_track("circle")
