@@ -507,6 +507,20 @@ def test_large_image_4000x3000(product, oracle):
         assert_same_state(g, o)
 
 
+@pytest.mark.parametrize("n_envs,cars,rays,policy", [(4101, 1, 36, "fast"), (1100, 3, 90, "nidc"), (517, 1, 360, "random")])
+def test_ragged_batches(product, oracle, n_envs, cars, rays, policy):
+    """Batch sizes that leave the last workgroup partly filled (8 cars per workgroup at 4101 envs, 12 at 1100 x 3, one at 517):
+    every env against the oracle after a closed loop."""
+    t = load_track("circle")
+    g, o = both(product, oracle, t, n_envs=n_envs, cars_per_env=cars, n_rays=rays, spawn_mode=1 if cars == 1 else 0, seed=8)
+    with g, o:
+        g.rollout(policy, 60); o.rollout(policy, 60)
+        assert_same_state(g, o)
+        g.reset(); o.reset()
+        g.rollout(policy, 7); o.rollout(policy, 7)
+        assert_same_state(g, o)
+
+
 def test_finished_cars_become_ghosts(product, oracle):
     """custom.py:1367-1371,1441-1466: a car that reached lap_target gets the null driver, stops colliding and is invisible."""
     t = load_track("circle")
