@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Long closed-loop comparison of the HIP library with the oracle (test infrastructure, like tests/): soak.py [steps] [envs]
+For every track and driver: a full-size batch on the GPU, its first `envs` envs on the oracle (env_base semantics make a prefix
+an identical sub-batch), compared bit for bit every `chunk` steps."""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np
+from ft_grandprix_amd import capi
+from ft_grandprix_amd.track import load_track
+from tests.helpers import load_oracle
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+envs = int(sys.argv[2]) if len(sys.argv) > 2 else 192
+chunk = 500
+lib, ora = capi.load(), load_oracle()
+bad = 0
+for name in ("track", "circle", "small-circle", "inkscape"):
+    t = load_track(name)
+    for policy, cars, rays in (("fast", 1, 1080), ("nidc", 1, 1080), ("random", 1, 1080), ("fast", 4, 360)):
+        n_big = 4096 if cars == 1 else 1024
+        kw = dict(cars_per_env=cars, n_rays=rays, spawn_mode=1 if cars == 1 else 0, seed=99)
+        t0 = time.time()
+        with capi.Env(lib, t, n_envs=n_big, **kw) as g, capi.Env(ora, t, n_envs=envs, **kw) as o:
+            ora.dll.oracle_set_threads(o.h, 16)
+            n = envs * cars
+            for done in range(0, steps, chunk):
+                g.rollout(policy, chunk); o.rollout(policy, chunk)
+                same = (np.array_equal(g.lidar()[:n], o.lidar()) and np.array_equal(g.progress()[:n], o.progress())
+                        and np.array_equal(g.pose()[:n], o.pose()) and np.array_equal(g.ctrl()[:n], o.ctrl()))
+                if not same:
+                    bad += 1
+                    print(f"MISMATCH {name} {policy} x{cars} after {done + chunk} steps", flush=True)
+                    break
+        print(f"{name:13s} {policy:7s} x{cars} {rays:5d} rays: {steps} steps, {envs} envs compared, {time.time() - t0:.0f} s", flush=True)
+print("soak:", "FAILED" if bad else "all identical")
+sys.exit(1 if bad else 0)
