@@ -34,7 +34,9 @@ struct alignas(16) LidarFrame {
     float u0, v0, chf, shf;       // LiDAR centre in pixels (binary32 of the binary64 value), heading (cos, sin) in binary32
     double lcx, lcy;              // LiDAR centre, world
     double x, y, qw, qz;          // pre-step pose
-    int32_t finished, pad0, pad1, pad2;
+    int32_t finished;
+    int32_t slot0;                // first car slot (inside the workgroup) of this car's env      } multi-car envs only:
+    float fx, fy;                 // binary32 of x, y: what the inter-vehicle cull compares        } see frame_write()
 };
 static_assert(sizeof(LidarFrame) == 80, "LidarFrame layout");
 

@@ -226,12 +226,12 @@ __device__ __forceinline__ void lidar_pool(const DeviceParams& P, const Lds& L, 
                 const float cull = L.veh->cull_radius;
                 const double lcx = me->lcx, lcy = me->lcy;
                 const float ox = (float)lcx - r0 * dxw, oy = (float)lcy - r0 * dyw;
-                const int slot0 = c - c % P.cars_per_env;
+                const int slot0 = me->slot0;
                 if (!me->finished)
                     for (int k = 0; k < P.cars_per_env; ++k) {
                         const LidarFrame* b = frames + slot0 + k;
                         if (slot0 + k == c || b->finished) continue;          // shadowed cars are invisible (custom.py:1441-1466)
-                        const float wx = (float)b->x - ox, wy = (float)b->y - oy;
+                        const float wx = b->fx - ox, wy = b->fy - oy;
                         const float along = wx * dxw + wy * dyw;
                         const float perp2 = (wx * wx + wy * wy) - along * along;
                         if (perp2 > cull * cull || along < -cull || (r >= 0.0f && along - cull > r)) continue;
@@ -562,7 +562,7 @@ __device__ __forceinline__ void car_contact(const DeviceParams& P, const FtgpVeh
 }
 
 // LiDAR frame of a car at its current pose (lidar_car() of the oracle: centre, heading, binary32 pixel coordinates)
-__device__ __forceinline__ void frame_write(const DeviceParams& P, const FtgpVehicle& v, const CarCore* st, LidarFrame* fr)
+__device__ __forceinline__ void frame_write(const DeviceParams& P, const FtgpVehicle& v, const CarCore* st, LidarFrame* fr, int slot)
 {
     const double qw = st->qw, qz = st->qz;
     const double ch = 1.0 - 2.0 * (qz * qz), sh = 2.0 * (qw * qz);
@@ -575,6 +575,10 @@ __device__ __forceinline__ void frame_write(const DeviceParams& P, const FtgpVeh
     fr->lcx = lcx; fr->lcy = lcy;
     fr->x = st->x; fr->y = st->y; fr->qw = qw; fr->qz = qz;
     fr->finished = finished;
+    if (sgpr(P.cars_per_env) > 1) {       // what the inter-vehicle cull reads (this function sits on the driver -> dynamics chain: nothing it does not need)
+        fr->slot0 = slot - slot % P.cars_per_env;
+        fr->fx = (float)st->x; fr->fy = (float)st->y;
+    }
 }
 
 // K1 + K3 for every car of the workgroup by ONE wave, four lanes per car (lane = 4 * car + r).
@@ -723,7 +727,7 @@ __device__ __forceinline__ void dynamics_lanes(const DeviceParams& P, const Lds&
     }
     wave_lds_sync();
     // the LiDAR frames of the next step (its sweep starts after the workgroup barrier that ends this step)
-    if (on && r == 0) frame_write(P, v, st, next_frames + c);
+    if (on && r == 0) frame_write(P, v, st, next_frames + c, c);
 }
 
 // Inclusive prefix sum over the 64 lanes of a wave with data-parallel-primitive moves (no LDS round trips): three shifts
@@ -950,7 +954,7 @@ __global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(cons
             for (int j = eighth + lane; j < R - eighth; j += FTGP_WAVE) row[scan_window_first(eighth) + j - eighth] = my_ranges[j];
         }
         wave_lds_sync();
-        if (lane == 0) frame_write(P, L.veh->v, L.cars + c, L.frame + c);
+        if (lane == 0) frame_write(P, L.veh->v, L.cars + c, L.frame + c, c);
     }
     if (threadIdx.x < 4) L.pool[threadIdx.x] = 0;
     }
