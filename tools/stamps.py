@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Phase timing of the step kernel from a -DFTGP_STAMPS diagnostic build: stamps.py lib.so [policy] [envs] [cars]"""
+"""Phase timing of the step kernel from a -DFTGP_STAMPS diagnostic build: stamps.py lib.so [policy] [envs] [cars] [track]"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from ft_grandprix_amd import capi
@@ -8,8 +8,9 @@ lib = capi.CLib(sys.argv[1], "ftgp_")
 policy = sys.argv[2] if len(sys.argv) > 2 else "fast"
 envs = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
 cars = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+track = sys.argv[5] if len(sys.argv) > 5 else "track"
 buf = (C.c_ulonglong * 16)()
-with capi.Env(lib, load_track("track"), n_envs=envs, cars_per_env=cars, n_rays=1080, spawn_mode=1 if cars == 1 else 0, seed=1234) as e:
+with capi.Env(lib, load_track(track), n_envs=envs, cars_per_env=cars, n_rays=1080, spawn_mode=1 if cars == 1 else 0, seed=1234) as e:
     e.rollout(policy, 100); e.last_kernel_ms(); lib.dll.ftgp_debug_stamps(buf)
     e.rollout(policy, 300); ms = e.last_kernel_ms(); lib.dll.ftgp_debug_stamps(buf)
 s = list(buf)
