@@ -15,12 +15,12 @@ import numpy as np
 
 from .track import Track
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 PATH_POINTS = 100
 MAX_LAP_TIMES = 32
 SNAPSHOT_DOUBLES = 10
 POSE_DOUBLES = 13
-PROGRESS_INTS = 9
+PROGRESS_INTS = 10
 METRIC_DOUBLES = 8
 
 POLICY_HOST, POLICY_LOBOTOMY, POLICY_NIDC, POLICY_FAST, POLICY_RANDOM = 0, 1, 2, 3, 4
@@ -28,7 +28,7 @@ POLICY_BY_NAME = {"host": POLICY_HOST, "lobotomy": POLICY_LOBOTOMY, "nidc": POLI
                   "fast": POLICY_FAST, "random": POLICY_RANDOM}
 
 PROGRESS_FIELDS = ("laps", "completion", "lap_completion", "absolute_completion", "finished",
-                   "off_track", "start", "good_start", "delta")
+                   "off_track", "start", "good_start", "delta", "finish_step")
 METRIC_FIELDS = ("steps", "n_cars", "sum_laps", "sum_absolute_completion", "n_finished",
                  "n_off_track", "min_lap_time", "max_lap_time")
 
@@ -68,7 +68,7 @@ class FtgpConfig(C.Structure):
 # every symbol include/ftgp.h declares (checked by tests/test_capi.py)
 API_SYMBOLS = (
     "default_vehicle", "tricycle_vehicle", "last_error", "device_count", "create", "destroy", "reset", "set_ctrl", "step",
-    "rollout", "get_lidar", "get_snapshot", "get_pose", "get_progress", "get_lap_times", "get_ctrl",
+    "rollout", "get_lidar", "get_snapshot", "get_pose", "get_progress", "get_winners", "get_lap_times", "get_ctrl",
     "get_steps", "set_pose", "policy_eval", "eval_progress", "metrics_local", "comm_unique_id", "comm_init", "metrics_allgather",
     "last_kernel_ms", "kernel_name", "fakelidar", "selftest",
 )
@@ -118,6 +118,7 @@ class CLib:
             "get_snapshot": (i32, [vp, dp]),
             "get_pose": (i32, [vp, dp]),
             "get_progress": (i32, [vp, dp]),
+            "get_winners": (i32, [vp, dp]),
             "get_lap_times": (i32, [vp, dp, dp]),
             "get_ctrl": (i32, [vp, dp]),
             "get_steps": (i32, [vp, dp]),
@@ -280,6 +281,12 @@ class Env:
         out = np.empty((self.n_cars, PROGRESS_INTS), dtype=np.int32)
         self._call("get_progress", _ptr(out))
         return out
+
+    def winners(self) -> np.ndarray:
+        """Place of each car among the finishers of its env (1 = winner, 0 = still racing): Mujoco.winners, custom.py:1367-1369."""
+        out = np.empty(self.n_cars, dtype=np.int32)
+        self._call("get_winners", _ptr(out))
+        return out.reshape(self.n_envs, self.cars_per_env)
 
     def lap_times(self):
         counts = np.empty(self.n_cars, dtype=np.int32)

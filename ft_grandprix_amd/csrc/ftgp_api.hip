@@ -346,6 +346,9 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
     if (t.width < 1 || t.height < 1 || !t.bits || !t.path || t.words_per_row < (t.width + 31) / 32)
         return fail(FTGP_ERR_ARG, "bad track%s");
     if (t.width > 8192 || t.height > 8192) return fail(FTGP_ERR_ARG, "images above 8192 pixels are not supported%s");
+    // the march addresses the box field with a 32-bit byte offset (ftgp_ray_offset: plane << 8 + cell offsets)
+    if ((uint64_t)ftgp_plane256(t.width, t.height) * 256u * FTGP_SECTORS > 0xFFFFFFFFull)
+        return fail(FTGP_ERR_ARG, "track image too large: the sector box field (64 bytes per pixel) must stay below 4 GiB (about 67 million pixels)%s");
     if (cfg->env_base < 0) return fail(FTGP_ERR_ARG, "env_base < 0%s");
     if (!(cfg->dt > 0.0) || !(t.px_size_x > 0.0) || !(t.px_size_y > 0.0)) return fail(FTGP_ERR_ARG, "bad dt / pixel size%s");
     const FtgpVehicle& v = cfg->vehicle;
@@ -694,6 +697,32 @@ int ftgp_get_progress(FtgpEnv* e, int32_t* out)
     return 0;
 }
 
+int ftgp_get_winners(FtgpEnv* e, int32_t* out)
+{
+    if (!e || !out) return fail(FTGP_ERR_ARG, "null argument%s");
+    if (int rc = sync_rows_to_host(e)) return rc;
+    // places in the order cars reached lap_target; cars that got there in the same step rank in car order, the order of the
+    // reference's per-car loop (custom.py:1337,1367-1369)
+    const int cpe = e->P.cars_per_env;
+    for (int env = 0; env < e->P.n_envs; ++env) {
+        const int32_t* p = e->h_prog.data() + (size_t)env * cpe * FTGP_PROGRESS_INTS;
+        for (int i = 0; i < cpe; ++i) {
+            int place = 0;
+            if (p[i * FTGP_PROGRESS_INTS + 4]) {
+                place = 1;
+                const int32_t mine = p[i * FTGP_PROGRESS_INTS + 9];
+                for (int k = 0; k < cpe; ++k)
+                    if (k != i && p[k * FTGP_PROGRESS_INTS + 4]) {
+                        const int32_t theirs = p[k * FTGP_PROGRESS_INTS + 9];
+                        if (theirs < mine || (theirs == mine && k < i)) ++place;
+                    }
+            }
+            out[(size_t)env * cpe + i] = place;
+        }
+    }
+    return 0;
+}
+
 int ftgp_get_lap_times(FtgpEnv* e, int32_t* counts, double* times)
 {
     if (!e || !counts || !times) return fail(FTGP_ERR_ARG, "null argument%s");
@@ -835,6 +864,10 @@ int ftgp_debug_stamps(unsigned long long* out)
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ftgp_stamps), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
     unsigned long long z[16] = { 0 };
     return hipMemcpyToSymbol(HIP_SYMBOL(ftgp_stamps), z, sizeof z) == hipSuccess ? 0 : -1;
+}
+int ftgp_debug_wg_times(unsigned long long* out, int n_blocks)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(ftgp_wg_times), sizeof(unsigned long long) * 2 * (size_t)n_blocks) == hipSuccess ? 0 : -1;
 }
 #endif
 

@@ -19,7 +19,9 @@ struct alignas(16) CarCore {
     double dist2;                 // squared distance to the centre-line (custom.py:1343)
     int32_t completion, laps, start, offset;
     int32_t good_start, finished, off_track, delta;
-    int32_t n_times, pad0, pad1, pad2;
+    int32_t n_times;
+    int32_t finish_step;          // env step at which `finished` was set (custom.py:1367-1370); meaningful while finished != 0
+    int32_t pad1, pad2;
 };
 // The lap-time list stays in HBM (written on lap crossings only).
 struct alignas(16) CarState : CarCore {

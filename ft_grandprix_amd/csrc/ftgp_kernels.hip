@@ -1,16 +1,20 @@
 // ftgp_kernels.hip -- HIP kernels of the ft_grandprix hot path for gfx950 (CDNA4, wave64).
 //
-//   ftgp_step_kernel<MULTI>   n_steps per launch, one workgroup = up to 16 cars (whole envs) and 16 waves, persistent.
-//       Per step the workgroup runs two phases separated by workgroup barriers:
-//         A  one wave per car: K5 driver on the car's previous scan (LDS) -> controls; LiDAR frame of the car's pose
-//         B  one wave: K1 integrate + K3 lap progress for ALL cars of the workgroup, one car per lane (K3: 4 lanes per car);
-//            every wave: K2 LiDAR sweep.  The rays of all cars form one pool (cars x n_rays); lanes take rays from it in
-//            index order and a wave refills its free lanes in batches, so no lane waits for another car's slowest ray.
-//       The sweep reads the LiDAR frames, never the live state, so K1 of step t runs beside K2 of step t (K1 needs the
-//       controls of step t and those depend only on the scan of step t-1).
+//   ftgp_step_kernel<MULTI>   n_steps per launch; one workgroup = whole envs, up to 16 cars on up to 16 waves (the headline shape
+//       is 8 cars on 16 waves, two workgroups per CU), persistent over all steps.  ONE workgroup barrier per step.  Inside a
+//       step, concurrently:
+//         K5       waves 0 .. cars-1, one car each: the driver on the car's PREVIOUS scan (the other LDS scan buffer) -> controls;
+//                  before it edits the scan window the wave flushes it to HBM as whole float4 groups (window_flush)
+//         K1 + K3  the wave whose driver delivers last: integrate + lap progress for ALL cars of the workgroup on four lanes per
+//                  car (dynamics_lanes), then the LiDAR frames of the NEXT step into the other frame buffer
+//         K2       every wave, as soon as its driver work is done: the sweep of THIS step.  The rays of all cars form one pool
+//                  (cars x n_rays); lanes take rays from it in index order and a wave refills its free lanes in batches, so no
+//                  lane waits for another car's slowest ray.
+//       The sweep reads the LiDAR frames, never the live state, and the scan a driver sees lags the pose by one step
+//       (custom.py:1395-1425): that is what makes the overlap legal.
 //       Staged into LDS once per launch with coalesced 16-B loads: parameter block, vehicle constants, centre-line, ray table,
-//       the cars' state records and the scan window the driver reads.  The march reads the sector box field from L2
-//       (ftgp_march.h); ranges go to HBM as 4-byte stores that merge in L2.
+//       the cars' state records and the scan windows the drivers read.  The march reads the sector box field from L2
+//       (ftgp_march.h); the rear quarter of a scan goes to HBM ray by ray (4-byte stores that merge in L2).
 //   ftgp_policy_kernel    K5 alone (ftgp_policy_eval).
 //   ftgp_reset_kernel     K4 reset / spawn (+ K3 at the spawn pose), one car per lane.
 //   ftgp_progress_kernel  K3 alone (after ftgp_set_pose), one car per lane.
@@ -175,6 +179,7 @@ __device__ __forceinline__ void rcp_abs2(float x, float y, float& rx, float& ry)
 // diagnostic build only (tools/stamps.sh): per-phase shader-clock totals over all workgroups and steps; never in the product
 #ifdef FTGP_STAMPS
 __device__ unsigned long long ftgp_stamps[16];
+__device__ unsigned long long ftgp_wg_times[8192][2];      // per workgroup: 100-MHz wall clock at entry and at exit (tools/wg_spread.py)
 #define STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
 #define STAMP_ADD(slot, dt) stamp_acc[slot] += (unsigned long long)(dt)
 #define STAMP_ARG , unsigned long long* stamp_acc
@@ -301,11 +306,18 @@ __device__ __forceinline__ void lidar_pool(const DeviceParams& P, const Lds& L, 
             if (alive) asm volatile("global_load_ushort %0, %1, %2\n\ts_waitcnt vmcnt(0)" : "+v"(w) : "v"(ftgp_ray_offset(ray)), "s"(field));
 #ifdef FTGP_PAD_VALU        // diagnostic (tools/valu_cost.sh): FTGP_PAD_VALU independent filler instructions per march iteration; what one more costs
             {   int pad0 = lane, pad1 = lane + 1; unsigned long long padm; double padd0 = 1.0, padd1 = 2.0;
+#ifdef FTGP_PAD_HALF        // the fillers with only lanes 0..31 enabled: does a wave64 instruction with an empty half issue in one pass?
+                int pad_exec_hi;
+                asm volatile("s_mov_b32 %0, exec_hi\n\ts_mov_b32 exec_hi, 0" : "=s"(pad_exec_hi));
+#endif
                 #pragma unroll
                 for (int q = 0; q < FTGP_PAD_VALU / 2; ++q) {      // %0 scratch VGPR, %1 SGPR pair (write-only), %2 scratch VGPR pair, %3 lane index, %4 SGPR mask
                     asm volatile(FTGP_PAD_ASM : "+v"(pad0), "=s"(padm), "+v"(padd0) : "v"(lane), "s"(live_mask) : "vcc");
                     asm volatile(FTGP_PAD_ASM : "+v"(pad1), "=s"(padm), "+v"(padd1) : "v"(lane), "s"(live_mask) : "vcc");
                 }
+#ifdef FTGP_PAD_HALF
+                asm volatile("s_mov_b32 exec_hi, %0" :: "s"(pad_exec_hi));
+#endif
             }
 #endif
             FtgpStep st;
@@ -367,7 +379,7 @@ __global__ void ftgp_selftest_rcp_kernel(unsigned long long* __restrict__ mismat
 // =============================================================================================
 // K3: lap progress (custom.py:1340-1372)
 // =============================================================================================
-struct Race { int32_t completion, laps, start, offset, good_start, finished, off_track, delta, n_times; double dist2; };
+struct Race { int32_t completion, laps, start, offset, good_start, finished, off_track, delta, n_times, finish_step; double dist2; };
 
 __device__ __forceinline__ void progress_update(const DeviceParams& P, Race& s, int64_t steps, int closest, double best, double* __restrict__ times)
 {
@@ -393,7 +405,10 @@ __device__ __forceinline__ void progress_update(const DeviceParams& P, Race& s, 
             s.good_start = 1;
         }
     }
-    if (s.laps >= P.lap_target) s.finished = 1;           // custom.py:1367-1370
+    if (s.laps >= P.lap_target) {                         // custom.py:1367-1370; the step of the first time orders the winners (custom.py:1368-1369)
+        if (!s.finished) s.finish_step = (int32_t)steps;
+        s.finished = 1;
+    }
     s.completion = completion;
 }
 
@@ -401,13 +416,13 @@ __device__ __forceinline__ void race_load(Race& r, const CarCore* st)
 {
     r.completion = st->completion; r.laps = st->laps; r.start = st->start; r.offset = st->offset;
     r.good_start = st->good_start; r.finished = st->finished; r.off_track = st->off_track; r.delta = st->delta;
-    r.n_times = st->n_times; r.dist2 = st->dist2;
+    r.n_times = st->n_times; r.finish_step = st->finish_step; r.dist2 = st->dist2;
 }
 __device__ __forceinline__ void race_store(const Race& r, CarCore* st)
 {
     st->completion = r.completion; st->laps = r.laps; st->start = r.start;
     st->good_start = r.good_start; st->finished = r.finished; st->off_track = r.off_track; st->delta = r.delta;
-    st->n_times = r.n_times; st->dist2 = r.dist2;
+    st->n_times = r.n_times; st->finish_step = r.finish_step; st->dist2 = r.dist2;
 }
 
 // =============================================================================================
@@ -925,6 +940,9 @@ __global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(cons
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = __builtin_amdgcn_readfirstlane(blockDim.x >> 6);
+#ifdef FTGP_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x < 8192) ftgp_wg_times[blockIdx.x][0] = __builtin_amdgcn_s_memrealtime();
+#endif
     // the parameter block itself goes to LDS: later reads come from there, not from ~70 pinned SGPRs
     stage16(lds + Pg->off_params, Pg, Pg->off_veh - Pg->off_params);
     stage16(lds + Pg->off_veh, Pg->veh_dev, Pg->off_path - Pg->off_veh);
@@ -989,9 +1007,12 @@ __global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(cons
             if (need_scan && it > 0) window_flush(P, scan_prev + c * win_floats, ci0 + c);     // the previous sweep's window, before the driver edits it
             if (policy != FTGP_POLICY_HOST) policy_apply(P, policy, scan_prev + c * win_floats, L.cars + c, ci0 + c, L.steps[c], L.list + wave * FTGP_WAVE, L.cover);
             wave_lds_sync();
+            // "my controls are in LDS" -> the wave that counts last reads every car's controls: release on this side (the
+            // fence of wave_lds_sync() + the RMW), acquire on the reader's (the RMW + the fence below), workgroup scope
             int n = 0;
-            if (lane == 0) n = atomicAdd(L.pool + 2 + par, 1);
+            if (lane == 0) n = __hip_atomic_fetch_add(L.pool + 2 + par, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
             n = __builtin_amdgcn_readfirstlane(n);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             STAMP(t1); STAMP_ADD(0, t1 - t0);
             if (n == ncars_here - 1) {            // every driver of the workgroup has delivered its controls
                 if (lane == 0) { L.pool[par ^ 1] = 0; L.pool[2 + (par ^ 1)] = 0; }     // the next step's counters (idle during this step)
@@ -1027,6 +1048,10 @@ __global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(cons
             reinterpret_cast<uint32_t*>(static_cast<CarCore*>(&P.cars[ci]))[lane] = reinterpret_cast<const uint32_t*>(L.cars + c)[lane];
         if (lane == 0 && ci % P.cars_per_env == 0) P.steps[ci / P.cars_per_env] = L.steps[c];
     }
+#ifdef FTGP_STAMPS
+    __syncthreads();
+    if (threadIdx.x == 0 && blockIdx.x < 8192) ftgp_wg_times[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 template __global__ void ftgp_step_kernel<false>(const DeviceParams*, int, int);
@@ -1150,7 +1175,7 @@ __global__ void ftgp_pack_kernel(DeviceParams P, int32_t* __restrict__ prog, dou
     const int lc = a.good_start ? a.completion : -(100 - a.completion);         // custom.py:132-140
     int32_t* o = prog + (size_t)ci * FTGP_PROGRESS_INTS;
     o[0] = a.laps; o[1] = a.completion; o[2] = lc; o[3] = a.laps * 100 + lc; o[4] = a.finished;   // custom.py:142-143
-    o[5] = a.off_track; o[6] = a.start; o[7] = a.good_start; o[8] = a.delta;
+    o[5] = a.off_track; o[6] = a.start; o[7] = a.good_start; o[8] = a.delta; o[9] = a.finished ? a.finish_step : -1;
     double* d = core + (size_t)ci * 16;
     d[0] = a.x; d[1] = a.y; d[2] = a.qw; d[3] = a.qz; d[4] = a.vx; d[5] = a.vy; d[6] = a.wz; d[7] = a.u_speed; d[8] = a.u_steer;
     d[9] = a.laps; d[10] = lc; d[11] = a.laps * 100 + lc; d[12] = (double)P.steps[ci / P.cars_per_env]; d[13] = a.n_times; d[14] = d[15] = 0.0;

@@ -22,7 +22,7 @@
 #include <stdint.h>
 #include <string.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define FTGP_HD __host__ __device__ __forceinline__
 #else
 #define FTGP_HD static inline
@@ -259,7 +259,7 @@ FTGP_HD float ftgp_march_one(const uint16_t* field, int W, int H, float eps, flo
     FtgpRay r; ftgp_ray_init(r, pu, pv, du, dv, fabsf(1.0f / du), fabsf(1.0f / dv), W, H, fstride, plane256);
     uint32_t w = FTGP_FIELD_OUT;
     for (int guard = 0; guard < 4 * 8192; ++guard) {
-        w = field[ftgp_ray_offset(r) >> 1];
+        w = field[(uint32_t)ftgp_ray_offset(r) >> 1];      // byte offsets are 32-bit unsigned (ftgp_create keeps the field below 4 GiB)
         FtgpStep st;
         const bool near = ftgp_ray_step(r, w, eps, st);
         const int t = near ? ftgp_ray_fix(r, st) : st.t;

@@ -96,17 +96,32 @@ class Rendezvous:
                     err, srv = e, None
             if srv is None:
                 raise OSError(f"rendezvous: no free port near {port}: {err}")
-            srv.settimeout(timeout)
+            deadline = time.time() + timeout
             got = 0
-            while got < world - 1:
-                c, _ = srv.accept()
-                c.settimeout(timeout); c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                h = self._recv_exact(c, len(hello) + 4)
-                r = struct.unpack("<i", h[len(hello):])[0]
-                if h[:len(hello)] != hello or not (0 < r < world) or self.peers[r] is not None:
-                    c.close(); continue                 # somebody else's client
-                c.sendall(b"OK"); self.peers[r] = c; got += 1
-            srv.close()
+            try:
+                while got < world - 1:
+                    left = deadline - time.time()
+                    if left <= 0:
+                        raise TimeoutError(f"rendezvous: {world - 1 - got} of {world - 1} ranks never connected")
+                    srv.settimeout(left)
+                    try:
+                        c, _ = srv.accept()
+                    except socket.timeout:
+                        continue
+                    # a stray, short or silent client (a port scanner, another job) must not take rank 0 down: its handshake
+                    # gets a short timeout of its own and any failure just drops that one connection
+                    try:
+                        c.settimeout(min(5.0, timeout)); c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                        h = self._recv_exact(c, len(hello) + 4)
+                        r = struct.unpack("<i", h[len(hello):])[0]
+                        if h[:len(hello)] != hello or not (0 < r < world) or self.peers[r] is not None:
+                            c.close(); continue                 # somebody else's client
+                        c.sendall(b"OK"); c.settimeout(timeout)
+                    except (OSError, ConnectionError):
+                        c.close(); continue
+                    self.peers[r] = c; got += 1
+            finally:
+                srv.close()
         else:
             deadline = time.time() + timeout
             while self.sock is None:

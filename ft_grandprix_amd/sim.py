@@ -8,6 +8,9 @@ What is mirrored (reference paths):
     ``speed, steering_angle = driver.process_lidar(...)``; an exception prints a message and leaves that
     car's previous controls in place -- custom.py:1395-1411,1421-1423
   * finished cars are handed the null driver -- custom.py:1367-1371,1446
+  * ``winners``: place of every finisher of a world, in the order cars reach ``lap_target`` -- custom.py:1125,1367-1369;
+    kept per env and derived from the device's finish step, so it is the same after one ``rollout()`` to the end of the race
+    as after stepping through it
   * ``reset()`` = Mujoco.reload(): drivers re-instantiated, race state cleared, cars re-spawned -- custom.py:1089-1128
 The physics / LiDAR / lap logic themselves run on the GPU behind ``capi.Env``.
 """
@@ -52,6 +55,14 @@ def quaternion_to_euler(w, x, y, z):
     pitch = math.asin(t2)
     yaw = math.atan2(2.0 * (w * z + x * y), 1.0 - 2.0 * (y * y + z * z))
     return [yaw, pitch, roll]
+
+
+def ordinal(n: int) -> str:
+    """1 -> '1st', 2 -> '2nd', 11 -> '11th', 0 -> '0th' ... the dashboard's position label (custom.py:47-55, used at custom.py:358)."""
+    text = str(n)
+    teen = len(text) > 1 and text[-2] == "1"
+    suffix = "th" if (text == "0" or teen) else {"1": "st", "2": "nd", "3": "rd"}.get(text[-1], "th")
+    return text + suffix
 
 
 def resolve_driver_path(spec: str) -> Optional[str]:
@@ -106,7 +117,7 @@ class Simulator:
         self.timestep = self.env.dt
         self.steps = 0
         self.vehicle_states: List[VehicleState] = []
-        self.winners = {}
+        self.winners: List[dict] = [{} for _ in range(n_envs)]      # per env: {vehicle id: place}, custom.py:1125,1368-1369
         self.reset()
 
     @staticmethod
@@ -128,20 +139,20 @@ class Simulator:
                                            label=car.get("name", f"car #{i}"), driver_path=path))
         self.vehicle_states = states
         self.steps = 0
-        self.winners = {}
+        self.winners = [{} for _ in range(self.n_envs)]
         self._sync_race_state()
 
     def _sync_race_state(self):
         prog = self.env.progress()
         counts, times = self.env.lap_times()
+        places = self.env.winners().reshape(-1)
         for vs in self.vehicle_states:
             p = prog[vs.id]
             vs.laps, vs.completion, vs.start, vs.delta = int(p[0]), int(p[1]), int(p[6]), int(p[8])
             vs.good_start, vs.off_track = bool(p[7]), bool(p[5])
             vs.times = [float(t) for t in times[vs.id, : min(int(counts[vs.id]), capi.MAX_LAP_TIMES)]]
             if p[4] and not vs.finished:           # custom.py:1367-1371 + 1446
-                if vs.id not in self.winners:
-                    self.winners[vs.id] = len(self.winners) + 1
+                self.winners[vs.id // self.cars_per_env][vs.id] = int(places[vs.id])
                 vs.finished = True
                 vs.driver = LobotomyDriver()
                 vs.v2 = False
@@ -174,6 +185,18 @@ class Simulator:
     def drive(self, n_steps: int):
         for _ in range(n_steps):
             self.step()
+
+    def rollout(self, policy: str, n_steps: int):
+        """n_steps with one of the on-device drivers ("nidc", "fast", "lobotomy", "random") for every car, in ONE launch; the
+        race state -- laps, lap times, finished, winners -- is the same as after n_steps single steps."""
+        self.env.rollout(policy, n_steps)
+        self.steps += n_steps
+        self._sync_race_state()
+
+    def podium(self, env: int = 0) -> List[int]:
+        """Vehicle ids of env's finishers, winner first (the order Mujoco.winners was filled in, custom.py:1368-1369)."""
+        w = self.winners[env]
+        return sorted(w, key=w.get)
 
     def ranking(self) -> List[int]:
         """Car ids by absolute completion, best first (the dashboard order of custom.py:335)."""

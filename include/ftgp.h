@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FTGP_ABI_VERSION 2
+#define FTGP_ABI_VERSION 3
 
 /* status codes */
 #define FTGP_OK              0
@@ -49,7 +49,8 @@ extern "C" {
 /* number of doubles / ints per car in the packed read-back rows */
 #define FTGP_SNAPSHOT_DOUBLES 10 /* laps, vel[3], yaw, pitch, roll, lap_completion, absolute_completion, time */
 #define FTGP_POSE_DOUBLES     13 /* qpos[7] = x y z qw qx qy qz ; qvel[6] = vx vy vz wx wy wz */
-#define FTGP_PROGRESS_INTS     9 /* laps, completion, lap_completion, absolute_completion, finished, off_track, start, good_start, delta */
+#define FTGP_PROGRESS_INTS    10 /* laps, completion, lap_completion, absolute_completion, finished, off_track, start, good_start, delta,
+                                    finish_step: the env step at which `finished` was set (custom.py:1367-1370), -1 while racing */
 #define FTGP_METRIC_DOUBLES    8 /* steps, n_cars, sum_laps, sum_abs_completion, n_finished, n_off_track, min_lap_time, max_lap_time */
 
 /*
@@ -189,8 +190,14 @@ int ftgp_get_snapshot(FtgpEnv *env, double *out);
 /* double[n_cars][FTGP_POSE_DOUBLES]; replaces joint.qpos / joint.qvel reads (custom.py:1340; 149-152). */
 int ftgp_get_pose(FtgpEnv *env, double *out);
 
-/* int32[n_cars][FTGP_PROGRESS_INTS]; replaces the VehicleState race fields (custom.py:91-143,1340-1372). */
+/* int32[n_cars][FTGP_PROGRESS_INTS]; replaces the VehicleState race fields (custom.py:91-143,1340-1372).
+ * finish_step orders the finishers of an env: the reference hands out places in the order cars reach lap_target, and within
+ * one step in car order (winners[id] = len(winners) + 1 inside the per-car loop, custom.py:1337,1367-1369) -- i.e. by
+ * (finish_step, car index).  It survives a multi-step ftgp_rollout, so one launch to the end of a race still says who won. */
 int ftgp_get_progress(FtgpEnv *env, int32_t *out);
+
+/* int32[n_cars]: place of each car among the finishers of its env, 1 = winner, 0 = still racing (Mujoco.winners, custom.py:1125,1367-1369). */
+int ftgp_get_winners(FtgpEnv *env, int32_t *out);
 
 /* counts: int32[n_cars]; times: double[n_cars][FTGP_MAX_LAP_TIMES]; replaces VehicleState.times (custom.py:124,1351-1363). */
 int ftgp_get_lap_times(FtgpEnv *env, int32_t *counts, double *times);

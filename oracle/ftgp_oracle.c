@@ -49,6 +49,7 @@ typedef struct Car {
     int32_t completion, laps, start, offset;
     int32_t good_start, finished, off_track, delta;
     int32_t n_times;
+    int32_t finish_step;     /* self.steps when `finished` was set (custom.py:1367-1370) */
     double times[FTGP_MAX_LAP_TIMES];
     double dist2;            /* distance_from_track (squared, custom.py:1343) */
     /* fast.py:12 */
@@ -67,6 +68,8 @@ struct OracleEnv {
     Car *cars;
     float *ranges;           /* [n_cars][n_rays] */
     int64_t *steps;          /* per env */
+    int32_t *place;          /* per car: Mujoco.winners[id] (custom.py:1125,1368-1369), 0 = not a winner yet */
+    int32_t *n_winners;      /* per env: len(self.winners) */
     double wheel_load[4];
     int lidar_mode;          /* 0 = f32 field-accelerated march (== 2 bit for bit), 1 = binary64 plain DDA, 2 = THE SPEC: f32 plain DDA */
     int threads;
@@ -464,7 +467,11 @@ static void progress_car(OracleEnv *e, int ci)
             a->good_start = 1;
         }
     }
-    if (a->laps >= e->cfg.lap_target) a->finished = 1;
+    if (a->laps >= e->cfg.lap_target) {              /* custom.py:1367-1370: winners[id] = len(winners) + 1 the first time */
+        if (!a->finished) a->finish_step = (int32_t)steps;
+        if (e->place[ci] == 0) e->place[ci] = ++e->n_winners[env];     /* kept the reference's way: a dict filled inside the per-car loop */
+        a->finished = 1;
+    }
     a->completion = completion;
 }
 
@@ -804,6 +811,8 @@ int oracle_create(const FtgpConfig *cfg, OracleEnv **out)
     e->cars = (Car *)calloc((size_t)e->n_cars, sizeof(Car));
     e->ranges = (float *)calloc((size_t)e->n_cars * R, sizeof(float));
     e->steps = (int64_t *)calloc((size_t)cfg->n_envs, sizeof(int64_t));
+    e->place = (int32_t *)calloc((size_t)e->n_cars, sizeof(int32_t));
+    e->n_winners = (int32_t *)calloc((size_t)cfg->n_envs, sizeof(int32_t));
     e->threads = 1;
     *out = e;
     extern int oracle_reset(OracleEnv *, const uint8_t *);
@@ -814,7 +823,7 @@ int oracle_destroy(OracleEnv *e)
 {
     if (!e) return 0;
     free(e->bits); free(e->field); free(e->ray_bx); free(e->ray_by); free(e->ray_bxd); free(e->ray_byd);
-    free(e->cars); free(e->ranges); free(e->steps); free(e);
+    free(e->cars); free(e->ranges); free(e->steps); free(e->place); free(e->n_winners); free(e);
     return 0;
 }
 
@@ -827,6 +836,8 @@ int oracle_reset(OracleEnv *e, const uint8_t *mask)
     for (int env = 0; env < e->cfg.n_envs; ++env) {
         if (mask && !mask[env]) continue;
         e->steps[env] = 0;
+        e->n_winners[env] = 0;                                           /* self.winners = {} (custom.py:1125) */
+        for (int k = 0; k < cpe; ++k) e->place[env * cpe + k] = 0;
         for (int k = 0; k < cpe; ++k) reset_car(e, env * cpe + k);
         for (int k = 0; k < cpe; ++k) progress_car(e, env * cpe + k);
     }
@@ -923,10 +934,11 @@ int oracle_get_progress(OracleEnv *e, int32_t *out)
         const Car *a = &e->cars[i]; int32_t *o = out + (size_t)i * FTGP_PROGRESS_INTS;
         int lc = lap_completion(a);
         o[0] = a->laps; o[1] = a->completion; o[2] = lc; o[3] = a->laps * 100 + lc; o[4] = a->finished;
-        o[5] = a->off_track; o[6] = a->start; o[7] = a->good_start; o[8] = a->delta;
+        o[5] = a->off_track; o[6] = a->start; o[7] = a->good_start; o[8] = a->delta; o[9] = a->finished ? a->finish_step : -1;
     }
     return 0;
 }
+int oracle_get_winners(OracleEnv *e, int32_t *out) { memcpy(out, e->place, sizeof(int32_t) * (size_t)e->n_cars); return 0; }
 int oracle_get_lap_times(OracleEnv *e, int32_t *counts, double *times)
 {
     for (int i = 0; i < e->n_cars; ++i) {

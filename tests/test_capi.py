@@ -52,6 +52,22 @@ def test_bad_arguments_are_rejected(oracle):
         capi.Env(oracle, t, n_envs=1, cars_per_env=9)
 
 
+def test_box_field_must_stay_addressable_with_32_bits(product):
+    """The march addresses the sector box field (32 planes x 2 bytes per pixel, ring included) with a 32-bit byte offset:
+    ftgp_create refuses an image whose field would reach 4 GiB instead of wrapping silently.  Error path only -- the check
+    sits in front of the device probe and allocates nothing (the bitmap pointer is never read)."""
+    class Huge:
+        width, height = 8192, 8192
+        px_size_x = px_size_y = 40.0 / 8192
+        origin_x, origin_y = 0.0, 0.0
+        bits = np.zeros((1, 256), dtype=np.uint32)          # one row stands in for the 256-MB bitmap; words_per_row is what is checked
+        path = np.zeros((100, 2))
+    with pytest.raises(capi.FtgpError) as ei:
+        capi.Env(product, Huge, n_envs=1, n_rays=8)
+    assert ei.value.code == -1 and "4 GiB" in str(ei.value)
+    assert (2 * 8194 * 8194 + 255) // 256 * 256 * 32 > 2 ** 32 > (2 * 8194 * 8183 + 255) // 256 * 256 * 32     # 8192 x 8181 is the last height that fits
+
+
 def test_product_package_never_references_the_oracle():
     pkg = os.path.join(ROOT, "ft_grandprix_amd")
     for dirpath, _, files in os.walk(pkg):

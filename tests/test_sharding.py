@@ -2,6 +2,7 @@
 import os
 import socket
 import sys
+import time
 
 import numpy as np
 import pytest
@@ -144,3 +145,46 @@ def test_world_size_3_tcp_rendezvous_without_torch(oracle):
     assert tot["ranks"] == world
     for k in capi.METRIC_FIELDS:
         assert tot[k] == ref[k], k
+
+
+def test_rendezvous_survives_stray_and_short_clients():
+    """a client that connects to the rendezvous port and sends garbage, too little, or nothing must be dropped,
+    not take rank 0 down; the real rank still gets in afterwards."""
+    import socket
+    import threading
+    port = _free_port()
+    box = {}
+
+    def rank0():
+        try:
+            box["r0"] = ftdist.Rendezvous(0, 2, "127.0.0.1", port, token="t-stray", timeout=30)
+        except Exception as exc:             # noqa: BLE001 - asserted below
+            box["err"] = exc
+    th = threading.Thread(target=rank0); th.start()
+    strays = []
+    deadline = time.time() + 10
+    while time.time() < deadline and len(strays) < 3:
+        try:
+            c = socket.create_connection(("127.0.0.1", port + 1), timeout=1.0)
+        except OSError:
+            time.sleep(0.05); continue
+        strays.append(c)
+        if len(strays) == 1:
+            c.sendall(b"GET / HTTP/1.0\r\n\r\n" + b"x" * 80)      # a full-length but foreign hello
+        elif len(strays) == 2:
+            c.sendall(b"abc"); c.close()                            # short, then gone
+        # the third one says nothing at all and stays open: only its own 5-s handshake timeout is spent on it
+    assert len(strays) == 3
+    r1 = ftdist.Rendezvous(1, 2, "127.0.0.1", port, token="t-stray", timeout=30)
+    th.join(timeout=30)
+    assert "err" not in box and not th.is_alive(), box.get("err")
+    r0 = box["r0"]
+    got = {}
+    t2 = threading.Thread(target=lambda: got.setdefault("a", r0.allgather_bytes(b"zero")))
+    t2.start()
+    assert r1.allgather_bytes(b"one") == [b"zero", b"one"]
+    t2.join(timeout=10)
+    assert got["a"] == [b"zero", b"one"]
+    for c in strays:
+        c.close()
+    r0.close(); r1.close()

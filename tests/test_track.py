@@ -140,10 +140,14 @@ def test_g7_bracket_matches_the_reference(tmp_path):
     for f in written:
         assert json.load(open(d / f)) == g["items"][f]
     assert [i["driver"] for i in items] == [g["items"][f]["driver"] for f in written]
-    # the default palette: CSS names, sorted; indices come from the same hash
-    it = bracket.compute_driver_files(str(d), silent=True, output_dir=str(tmp_path))
-    pal = bracket.default_palette()
-    assert it[0]["primary"] == pal[bracket.Hasher(10).hash("drivers.alpha") % len(pal)]
+    # the DEFAULT palette (assets/bracket_palette.json) is the table the reference indexes: same files without palette=
+    assert bracket.default_palette() == g["palette"]
+    out = tmp_path / "defaults"; out.mkdir()
+    said = []
+    bracket.compute_driver_files(str(d), output_dir=str(out), report=said.append)
+    assert sorted(os.listdir(out)) == g["written"] and len(said) >= len(g["written"])
+    for f in g["written"]:
+        assert json.load(open(out / f)) == g["items"][f]
 
 
 def test_user_track_from_png_and_svg_through_the_oracle(oracle, tmp_path):

@@ -1,0 +1,162 @@
+"""f-3: who won.  The reference hands out places in the order cars reach lap_target -- ``winners[id] = len(winners) + 1``
+inside the per-car loop of the step (custom.py:1337,1367-1369) -- so within one step the lower car index ranks first.
+
+The oracle keeps that dict literally (``place`` / ``n_winners``); the product keeps only the step at which ``finished`` was set
+and derives the places from (finish_step, car index).  These tests drive both through the C-ABI surface: the CPU half pins the
+derivation rule against the oracle's dict, the GPU half (marked) pins libftgp.so against the oracle, including ONE ftgp_rollout
+that runs a four-car race to its end.
+"""
+import numpy as np
+import pytest
+
+from ft_grandprix_amd import capi
+from ft_grandprix_amd.sim import Simulator, ordinal
+from ft_grandprix_amd.track import load_track
+from tests.helpers import golden
+
+
+def places_from_finish_step(progress, n_envs, cars_per_env):
+    """The rule of include/ftgp.h (ftgp_get_winners), restated with numpy: rank by (finish_step, car index) among finishers."""
+    fin = progress[:, 4].reshape(n_envs, cars_per_env).astype(bool)
+    step = progress[:, 9].reshape(n_envs, cars_per_env)
+    out = np.zeros((n_envs, cars_per_env), dtype=np.int32)
+    for e in range(n_envs):
+        order = sorted((int(step[e, i]), i) for i in range(cars_per_env) if fin[e, i])
+        for place, (_, i) in enumerate(order, start=1):
+            out[e, i] = place
+    return out
+
+
+def teleport_schedule(env, track, crossing_step):
+    """Teleports every car along its own lap -- 30 %, 60 %, 95 % and, at its crossing step, over its start line -- with one
+    physics step after each teleport (the step ends with the progress block at the pose it reached).  Returns the poses used."""
+    path = np.asarray(track.path)
+    base = env.pose()
+    offsets = [int(np.argmin(((path - base[i, :2]) ** 2).sum(1))) for i in range(env.n_cars)]     # spawn index = VehicleState.offset
+    last = max(crossing_step)
+    for s in range(1, last + 1):
+        pose = base.copy()
+        for i in range(env.n_cars):
+            cs = crossing_step[i % len(crossing_step)]
+            q = 2 if s >= cs else (30, 60, 95)[min(s, 3) - 1]
+            k = (offsets[i] + q) % 100
+            d = path[(k + 1) % 100] - path[k]
+            ang = np.arctan2(d[1], d[0])
+            pose[i, 0:2] = path[k]
+            pose[i, 3], pose[i, 6] = np.cos(ang / 2), np.sin(ang / 2)
+            pose[i, 7:] = 0.0
+        env.set_pose(pose)
+        env.step(1)
+
+
+def spread_race(env, track):
+    """Four cars a quarter of a lap apart, each facing along the centre-line: car i has (100 - 25 i) % of a lap to its own line."""
+    path = np.asarray(track.path)
+    pose = env.pose()
+    for ci in range(env.n_cars):
+        e, i = divmod(ci, env.cars_per_env)
+        off = int(np.argmin(((path - pose[ci, :2]) ** 2).sum(1)))
+        k = (off + 25 * i + e % 3) % 100
+        d = path[(k + 1) % 100] - path[k]
+        ang = np.arctan2(d[1], d[0])
+        pose[ci, 0:2] = path[k]
+        pose[ci, 3], pose[ci, 6] = np.cos(ang / 2), np.sin(ang / 2)
+        pose[ci, 7:] = 0.0
+    env.set_pose(pose)
+    env.eval_progress()
+
+
+CROSSING = (7, 5, 4, 5)              # car 0 .. 3 cross their lines at these steps (after 30 %, 60 %, 95 %): places 4, 2, 1, 3 -- cars 1 and 3 tie: car order
+
+
+def test_same_step_finishers_rank_in_car_order(oracle):
+    t = load_track("circle")
+    with capi.Env(oracle, t, n_envs=3, cars_per_env=4, n_rays=36, lap_target=1) as o:
+        teleport_schedule(o, t, CROSSING)
+        p = o.progress()
+        assert (p[:, 4] == 1).all() and (p[:, 0] == 1).all()
+        np.testing.assert_array_equal(p[:, 9].reshape(3, 4), [list(CROSSING)] * 3)        # finish_step = self.steps of the crossing
+        np.testing.assert_array_equal(o.winners(), [[4, 2, 1, 3]] * 3)                     # the oracle's dict, filled car by car
+        np.testing.assert_array_equal(places_from_finish_step(p, 3, 4), o.winners())       # the product's rule gives the same
+        o.reset(np.array([0, 1, 0], dtype=np.uint8))                                       # self.winners = {} on reload (custom.py:1125)
+        np.testing.assert_array_equal(o.winners(), [[4, 2, 1, 3], [0, 0, 0, 0], [4, 2, 1, 3]])
+        assert (o.progress()[4:8, 9] == -1).all()
+
+
+def test_one_rollout_to_the_end_of_a_race_keeps_the_order(oracle):
+    """nidc on `circle`, lap_target 1: the places after ONE 18000-step rollout equal those collected while stepping through
+    the same race in chunks (where the order of arrival is observed from outside)."""
+    t = load_track("circle")
+    kw = dict(n_envs=8, cars_per_env=4, n_rays=90, lap_target=1, spawn_mode=1, seed=5)
+    with capi.Env(oracle, t, **kw) as one, capi.Env(oracle, t, **kw) as chunks:
+        for e in (one, chunks):
+            oracle.dll.oracle_set_threads(e.h, 8)
+            spread_race(e, t)
+        one.rollout("nidc", 18000)
+        seen = np.zeros((8, 4), dtype=np.int32)                  # places as an observer polling `finished` every 250 steps would assign
+        for _ in range(72):
+            chunks.rollout("nidc", 250)
+            fin = chunks.progress()[:, 4].reshape(8, 4).astype(bool)
+            for e in range(8):
+                new = [i for i in range(4) if fin[e, i] and seen[e, i] == 0]
+                assert len(new) <= 1, "two cars of an env finished inside one 250-step window: pick another seed"
+                for i in new:
+                    seen[e, i] = seen[e].max() + 1
+        np.testing.assert_array_equal(one.progress(), chunks.progress())
+        np.testing.assert_array_equal(one.winners(), seen)
+        np.testing.assert_array_equal(places_from_finish_step(one.progress(), 8, 4), seen)
+        assert (seen.max(1) >= 2).sum() >= 4 and len({tuple(r) for r in seen.tolist()}) >= 3      # real races, different outcomes
+
+
+def test_simulator_winners_are_per_env_and_survive_a_rollout(oracle):
+    t = load_track("circle")
+    cars = [{"driver": "ft_grandprix_amd.sim", "name": f"car {i}"} for i in range(4)]       # no Driver class there: null drivers
+    sim = Simulator(t, cars, n_envs=8, n_rays=90, lap_target=1, lib=oracle, spawn_mode=1, seed=5)
+    oracle.dll.oracle_set_threads(sim.env.h, 8)
+    spread_race(sim.env, t)
+    sim.rollout("nidc", 18000)
+    w = sim.env.winners()
+    for e in range(8):
+        assert sim.winners[e] == {e * 4 + i: int(w[e, i]) for i in range(4) if w[e, i]}
+        assert sim.podium(e) == [e * 4 + i for i in np.argsort(np.where(w[e] > 0, w[e], 99)) if w[e, i]]
+    assert all(vs.finished == bool(w[vs.id // 4, vs.id % 4]) for vs in sim.vehicle_states)
+    assert sim.steps == 18000
+    sim.close()
+
+
+def test_ordinal_matches_the_reference_table():
+    """custom.py:47-55 on 0 .. 124 (fixture G4)."""
+    ref = np.load(golden("g4_math.npz"))["ordinals"]
+    assert [ordinal(n) for n in range(len(ref))] == [str(s) for s in ref]
+
+
+# ---------------------------------------------------------------- the product (libftgp.so) against the oracle
+@pytest.mark.gpu
+def test_gpu_same_step_finishers_rank_in_car_order(product, oracle):
+    t = load_track("circle")
+    kw = dict(n_envs=3, cars_per_env=4, n_rays=36, lap_target=1)
+    with capi.Env(product, t, **kw) as g, capi.Env(oracle, t, **kw) as o:
+        for e in (g, o):
+            teleport_schedule(e, t, CROSSING)
+        np.testing.assert_array_equal(g.progress(), o.progress())
+        np.testing.assert_array_equal(g.winners(), o.winners())
+        np.testing.assert_array_equal(g.winners(), [[4, 2, 1, 3]] * 3)
+
+
+@pytest.mark.gpu
+def test_gpu_four_car_race_in_one_rollout(product, oracle):
+    """4 cars, nidc, circle, lap_target 1, ONE ftgp_rollout to the end: winners and ranking."""
+    t = load_track("circle")
+    kw = dict(n_envs=8, cars_per_env=4, n_rays=90, lap_target=1, spawn_mode=1, seed=5)
+    with capi.Env(product, t, **kw) as g, capi.Env(oracle, t, **kw) as o:
+        oracle.dll.oracle_set_threads(o.h, 8)
+        for e in (g, o):
+            spread_race(e, t)
+            e.rollout("nidc", 18000)
+        pg, po = g.progress(), o.progress()
+        np.testing.assert_array_equal(pg, po)                                   # incl. finish_step
+        np.testing.assert_array_equal(g.winners(), o.winners())                 # derived vs the reference's dict
+        assert (g.winners().max(1) >= 2).sum() >= 4
+        rank_g = np.argsort(-pg[:, 3].reshape(8, 4), axis=1, kind="stable")     # dashboard order by absolute_completion (custom.py:335)
+        rank_o = np.argsort(-po[:, 3].reshape(8, 4), axis=1, kind="stable")
+        np.testing.assert_array_equal(rank_g, rank_o)

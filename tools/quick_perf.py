@@ -6,6 +6,8 @@ from ft_grandprix_amd import capi
 from ft_grandprix_amd.track import load_track
 libs = sys.argv[1:] or [capi.product_library_path()]
 cases = (("track", "fast", 4096, 1, 300), ("circle", "nidc", 1024, 1, 300), ("track", "fast", 4096, 4, 100), ("track", "random", 4096, 1, 300))
+if os.environ.get("QUICK_CASES"):          # e.g. QUICK_CASES=0,2: only those rows
+    cases = tuple(cases[int(i)] for i in os.environ["QUICK_CASES"].split(","))
 for path in libs:
     lib = capi.CLib(path, "ftgp_")
     out = []
