@@ -306,18 +306,11 @@ __device__ __forceinline__ void lidar_pool(const DeviceParams& P, const Lds& L, 
             if (alive) asm volatile("global_load_ushort %0, %1, %2\n\ts_waitcnt vmcnt(0)" : "+v"(w) : "v"(ftgp_ray_offset(ray)), "s"(field));
 #ifdef FTGP_PAD_VALU        // diagnostic (tools/valu_cost.sh): FTGP_PAD_VALU independent filler instructions per march iteration; what one more costs
             {   int pad0 = lane, pad1 = lane + 1; unsigned long long padm; double padd0 = 1.0, padd1 = 2.0;
-#ifdef FTGP_PAD_HALF        // the fillers with only lanes 0..31 enabled: does a wave64 instruction with an empty half issue in one pass?
-                int pad_exec_hi;
-                asm volatile("s_mov_b32 %0, exec_hi\n\ts_mov_b32 exec_hi, 0" : "=s"(pad_exec_hi));
-#endif
                 #pragma unroll
                 for (int q = 0; q < FTGP_PAD_VALU / 2; ++q) {      // %0 scratch VGPR, %1 SGPR pair (write-only), %2 scratch VGPR pair, %3 lane index, %4 SGPR mask
                     asm volatile(FTGP_PAD_ASM : "+v"(pad0), "=s"(padm), "+v"(padd0) : "v"(lane), "s"(live_mask) : "vcc");
                     asm volatile(FTGP_PAD_ASM : "+v"(pad1), "=s"(padm), "+v"(padd1) : "v"(lane), "s"(live_mask) : "vcc");
                 }
-#ifdef FTGP_PAD_HALF
-                asm volatile("s_mov_b32 exec_hi, %0" :: "s"(pad_exec_hi));
-#endif
             }
 #endif
             FtgpStep st;

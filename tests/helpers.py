@@ -69,3 +69,64 @@ def write_template_track(template_dir, name="generated", width=640, height=480, 
         f.write(f'<?xml version="1.0"?>\n<svg xmlns="http://www.w3.org/2000/svg" width="{width}" height="{height}">'
                 f'<g transform="translate(3,4)"><path d="{d}"/></g></svg>\n')
     return wall
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# K2 (the rangefinder sweep) against the only LiDAR arithmetic the reference owns: raycast.fakelidar (fixture G2).
+def lidar_from_pixel_origins(lib, track, origins_px, yaw_world, n_rays):
+    """One env per origin: the car is posed so that its LiDAR centre sits on the pixel position origins_px[k] (wall frame of
+    `track`) with heading yaw_world[k]; returns (ranges [n, R] in world units, the vehicle constants)."""
+    from ft_grandprix_amd import capi
+    n = len(origins_px)
+    with capi.Env(lib, track, n_envs=n, n_rays=n_rays) as e:
+        v = e.cfg.vehicle
+        pose = e.pose()
+        cx = track.origin_x + origins_px[:, 0] * track.px_size_x
+        cy = track.origin_y - origins_px[:, 1] * track.px_size_y
+        c, s = np.cos(yaw_world), np.sin(yaw_world)
+        pose[:, 0] = cx - (c * v.lidar_x - s * v.lidar_y)
+        pose[:, 1] = cy - (s * v.lidar_x + c * v.lidar_y)
+        pose[:, 3], pose[:, 6] = np.cos(yaw_world / 2), np.sin(yaw_world / 2)
+        pose[:, 7:] = 0.0
+        e.set_pose(pose)
+        e.step(1)                                  # sensors are evaluated at the pose the step starts from
+        return e.lidar().astype(np.float64), float(v.lidar_ring_radius)
+
+
+def k2_minus_fakelidar_square_pixels(lib, name, R):
+    """Differences (pixels) between K2's range measured from the LiDAR centre and the reference's own fakelidar scans of fixture
+    G2, ray by ray, on the bitmap of track `name` taken with SQUARE pixels (fakelidar works in pixel space, so this is the frame
+    in which its uniform fan and K2's coincide).  G2 ray k has the image-frame angle yaw_g + pi - 2 pi k / R (custom.py:1387);
+    K2 ray j of a car with world yaw psi has -(psi + pi + 2 pi j / R) (mushr.em.xml:112-117, y up): the same ray for psi = -yaw_g."""
+    import dataclasses
+    from ft_grandprix_amd.track import load_track
+    g = np.load(golden("g2_fakelidar.npz"))
+    t = load_track(name)
+    s = 40.0 / t.width
+    sq = dataclasses.replace(t, px_size_x=s, px_size_y=s)
+    origins, ang, scan = g[f"{name}_origins"], g[f"{name}_{R}_angles"], g[f"{name}_{R}_scan"]
+    yaw_g = ang[:, 0] - np.pi
+    rng, r0 = lidar_from_pixel_origins(lib, sq, origins, -yaw_g, R)
+    assert (rng > 0).all()                          # every origin is enclosed by walls
+    return (rng - r0) / s - scan                    # K2 starts its rays r0 behind the centre
+
+
+def k2_minus_fakelidar_along_k2_rays(lib, name, R, seed=11):
+    """The same comparison in the track's REAL wall frame (non-square pixels on the 2133-px tracks): K2's world-space fan is not
+    uniform in pixel space there, so fakelidar -- the library's restatement, itself pinned bit for bit to G2 -- is evaluated
+    along K2's own pixel-space directions.  Returns the differences in pixels along each ray."""
+    from scipy.ndimage import distance_transform_edt
+    from ft_grandprix_amd import capi
+    from ft_grandprix_amd.track import load_track
+    g = np.load(golden("g2_fakelidar.npz"))
+    t = load_track(name)
+    origins = g[f"{name}_origins"]
+    yaw = np.random.default_rng(seed).uniform(-np.pi, np.pi, len(origins))
+    rng, r0 = lidar_from_pixel_origins(lib, t, origins, yaw, R)
+    a = yaw[:, None] + np.pi + 2 * np.pi * np.arange(R)[None, :] / R            # world angle of ray j
+    du, dv = np.cos(a) / t.px_size_x, -np.sin(a) / t.px_size_y                   # pixels per world unit of range
+    scale = np.hypot(du, dv)
+    dt = np.ascontiguousarray(distance_transform_edt(~t.wall_mask()), dtype=np.float64)
+    scan, _ = capi.fakelidar(lib, dt, origins, du / scale, dv / scale)
+    assert (rng > 0).all()
+    return (rng - r0) * scale - scan

@@ -5,5 +5,4 @@ timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.lo
 timeout -k 10 300 python3 tools/launch_sweep.py > gpurun_out/launch_sweep.log 2>&1 || exit 1; cat gpurun_out/launch_sweep.log
 timeout -k 10 300 bash tools/stamps.sh fast > gpurun_out/stamps.log 2>&1 || exit 1; cat gpurun_out/stamps.log
 timeout -k 10 300 python3 tools/wg_spread.py gpurun_out/libftgp_stamps.so fast 4096 1 20 100 500 > gpurun_out/wg_spread.log 2>&1 || exit 1; cat gpurun_out/wg_spread.log
-timeout -k 10 600 bash tools/half_exec.sh > gpurun_out/half_exec.log 2>&1 || exit 1; cat gpurun_out/half_exec.log
 timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 > gpurun_out/bench20.log 2>&1 || exit 1; tail -1 gpurun_out/bench20.log
