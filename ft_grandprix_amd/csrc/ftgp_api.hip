@@ -192,7 +192,7 @@ int lds_layout(DeviceParams& P, int cpb, int wpb)
     P.off_steps = o;  o += pad16((size_t)cpb * sizeof(int64_t));
     P.off_scan = o;   o += 2 * cpb * P.win_floats * (int)sizeof(float);   // double-buffered by step parity
     P.off_list = o;   o += std::min(cpb, wpb) * FTGP_WAVE * (int)sizeof(int);                 // driver scratch: wave c runs the driver of car c
-    P.off_pool = o;   o += 16;
+    P.off_pool = o;   o += 32;
     P.off_k1 = o;     o += cpb * (FTGP_FORCE_TERMS * 24 + 4 * 8 + 104);                         // K1 staging: force terms | new wheel spins | new state
     P.off_cover = o;  o += pad16(sizeof(float) * (size_t)(P.cover_kmax + 1));             // cover-count thresholds of the launch's driver (last: its size = lds_bytes - off_cover)
     P.lds_bytes = o;
@@ -416,6 +416,8 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
     }
     P.win_floats = ((P.eighth & 3) + (cfg->n_rays - 2 * P.eighth) + 1 + 3) & ~3;       // window at float (eighth % 4), ranges[0] in the last float
     P.snap_eps = ftgp_snap_eps(t.width, t.height);
+    { hipDeviceProp_t prop; CREATE_TRY(hipGetDeviceProperties(&prop, e->device)); P.n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256; }
+    P.edge_margin = (float)(v.lidar_ring_radius * std::max(P.inv_px_x, P.inv_px_y) * 1.001 + 2.0);
     P.ray_magic = (uint32_t)((0x100000000ull + (uint64_t)cfg->n_rays - 1) / (uint64_t)cfg->n_rays);
 
     // workgroup shape: whole envs, at most 16 cars (K1 / K3 run on the lanes of one wave), two workgroups per CU
@@ -867,7 +869,7 @@ int ftgp_debug_stamps(unsigned long long* out)
 }
 int ftgp_debug_wg_times(unsigned long long* out, int n_blocks)
 {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(ftgp_wg_times), sizeof(unsigned long long) * 2 * (size_t)n_blocks) == hipSuccess ? 0 : -1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(ftgp_wg_times), sizeof(unsigned long long) * 4 * (size_t)n_blocks) == hipSuccess ? 0 : -1;
 }
 #endif
 

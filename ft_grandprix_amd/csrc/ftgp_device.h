@@ -59,7 +59,9 @@ struct DeviceParams {
     // step-kernel launch shape and LDS layout (byte offsets, all 16-B aligned)
     int32_t cars_per_block, waves_per_block, eighth, win_floats;   // win_floats: floats per LDS scan row: (eighth % 4) + (n_rays - 2*eighth) + 1, padded to 4
     int32_t off_params, off_veh, off_path, off_ray, off_cars, off_frame, off_steps, off_scan, off_list, off_pool, off_k1, off_cover, lds_bytes, cover_kmax;
-    int32_t bubble_wrap, pad_b;   // custom.py:1041-1055: the four wheel softeners collide with the walls
+    int32_t bubble_wrap;          // custom.py:1041-1055: the four wheel softeners collide with the walls
+    int32_t n_cu, pad_c;          // compute units of the device (sweep_priority)
+    float edge_margin, pad_d;     // pixels: a LiDAR centre at least this far from every image edge has all its ray origins on the image (frame_write)
     const uint16_t* field;        // [FTGP_SECTORS][height + 2][width + 2] box entries (ftgp_march.h), HBM/L2
     const uint32_t* bits;         // [height][words_per_row] wall bitmap
     const uint32_t* nearbits;     // [height][words_per_row] wall bitmap dilated by contact_reach (early-out of the wall contact)

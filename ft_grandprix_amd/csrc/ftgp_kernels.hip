@@ -42,7 +42,8 @@ struct Lds {
     int64_t* steps;
     float* scan;              // [2][cars_per_block][win_floats] scan windows (layout: scan_window_* below), double-buffered by step parity
     int* list;                // [waves_per_block][64] driver scratch
-    int* pool;                // [2] next ray of the sweep, [2] drivers finished -- both double-buffered by step parity
+    int* pool;                // [2] next ray of the sweep, [2] drivers finished, [2] "some LiDAR frame is not known to lie well inside the image"
+                              // (frame_write) -- all double-buffered by step parity
     Force* terms;             // [cars_per_block][FTGP_FORCE_TERMS] K1 staging: force terms in the order they are summed
     double* wnew;             // [cars_per_block][4] K1 staging: new wheel spins
     Dyn* next;                // [cars_per_block] K1 staging: new dynamic state before the commit
@@ -179,7 +180,7 @@ __device__ __forceinline__ void rcp_abs2(float x, float y, float& rx, float& ry)
 // diagnostic build only (tools/stamps.sh): per-phase shader-clock totals over all workgroups and steps; never in the product
 #ifdef FTGP_STAMPS
 __device__ unsigned long long ftgp_stamps[16];
-__device__ unsigned long long ftgp_wg_times[8192][2];      // per workgroup: 100-MHz wall clock at entry and at exit (tools/wg_spread.py)
+__device__ unsigned long long ftgp_wg_times[8192][4];      // per workgroup: 100-MHz wall clock at entry and at exit, HW_ID, XCC_ID (tools/wg_spread.py)
 #define STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
 #define STAMP_ADD(slot, dt) stamp_acc[slot] += (unsigned long long)(dt)
 #define STAMP_ARG , unsigned long long* stamp_acc
@@ -191,9 +192,26 @@ __device__ unsigned long long ftgp_wg_times[8192][2];      // per workgroup: 100
 #define STAMP_PASS
 #endif
 
+// Two workgroups share a CU, and the hardware arbitrates vector issue by priority first and age second: left alone, the
+// workgroup that was dispatched first wins every contested cycle, finishes a launch ~20 % ahead of its partner and leaves the CU
+// half empty (four waves per SIMD, too few to keep the vector pipe full) for the rest of it.  So the two take turns: a 100-MHz
+// wall-clock bit that both see picks which of them sweeps at the raised priority.  "Workgroups b and b + (number of CUs) are
+// partners" is only what the dispatcher is observed to do (the hardware promises no order); a wrong guess costs fairness,
+// never correctness.
+#ifndef FTGP_FAIR_SHIFT
+#define FTGP_FAIR_SHIFT 13        // turns of 2^13 ticks = 82 us (measured: 2^12 .. 2^15 are equally good, shorter and longer turns worse)
+#endif
+__device__ __forceinline__ void sweep_priority(bool second_half)
+{
+#ifndef FTGP_NO_FAIR
+    const bool mine = (((uint32_t)__builtin_amdgcn_s_memrealtime() >> FTGP_FAIR_SHIFT) & 1u) != (second_half ? 1u : 0u);
+    if (mine) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#endif
+}
+
 template <bool MULTI>
 __device__ __forceinline__ void lidar_pool(const DeviceParams& P, const Lds& L, const LidarFrame* frames, float* scan_rows, int* pool,
-                                           int ncars_here, int ci0, bool scan_lds STAMP_ARG)
+                                           int ncars_here, int ci0, bool scan_lds, bool second_half STAMP_ARG)
 {
     typedef const __attribute__((address_space(1))) unsigned char* global_u8;
     typedef __attribute__((address_space(1))) float* global_f32;
@@ -208,6 +226,7 @@ __device__ __forceinline__ void lidar_pool(const DeviceParams& P, const Lds& L, 
     const global_u8 field = (global_u8)uniform_ptr(P.field);
     const global_f32 ranges = (global_f32)uniform_ptr(P.ranges) + (size_t)ci0 * stride;
     const int lane = lane_here();
+    const bool all_safe = sgpr(pool[4]) == 0;        // every ray of this sweep starts on the image (frame_write): no test per ray
 
     FtgpRay ray; ftgp_ray_park(ray, -1.0f);
     float dxw = 0.0f, dyw = 0.0f;
@@ -218,6 +237,7 @@ __device__ __forceinline__ void lidar_pool(const DeviceParams& P, const Lds& L, 
     uint64_t live_mask = 0;          // lanes whose ray is still on its way (wave-uniform)
     for (int round = 0; round < (1 << 20); ++round) {
         STAMP(ta);
+        sweep_priority(second_half);
         // ---- finished rays: store the range ...
         if (done && cj >= 0) {
             const int c = cj >> 16, j = cj & 0xffff;
@@ -286,10 +306,13 @@ __device__ __forceinline__ void lidar_pool(const DeviceParams& P, const Lds& L, 
                 const float pv = fmaf(dv, -r0, f4.y);
                 float ivx, ivy;
                 rcp_abs2(du, dv, ivx, ivy);
-                ftgp_ray_init(ray, pu, pv, du, dv, ivx, ivy, W, H, fstride, plane256);
-                // a finished car's rangefinders are switched off (custom.py:1436-1439): its frame carries u0 = -inf, so the ray is
-                // parked like any ray that starts off the image, and reads 0 instead of -1
-                ray.result = (f4.x == -INFINITY) ? 0.0f : -1.0f;
+                ftgp_ray_init(ray, pu, pv, du, dv, ivx, ivy, W, H, fstride, plane256, true);      // result stays -1 (ftgp_ray_park above)
+                if (!all_safe) {         // wave-uniform, rare: some car of the workgroup is near the image edge, off it, or has finished
+                    ftgp_ray_park_if_outside(ray, pu, pv, W, H);
+                    // a finished car's rangefinders are switched off (custom.py:1436-1439): its frame carries u0 = -inf, so the ray is
+                    // parked like any ray that starts off the image, and reads 0 instead of -1
+                    ray.result = (f4.x == -INFINITY) ? 0.0f : -1.0f;
+                }
             }
             pool_empty = base + nfree >= total;
         }
@@ -569,16 +592,20 @@ __device__ __forceinline__ void car_contact(const DeviceParams& P, const FtgpVeh
     }
 }
 
-// LiDAR frame of a car at its current pose (lidar_car() of the oracle: centre, heading, binary32 pixel coordinates)
-__device__ __forceinline__ void frame_write(const DeviceParams& P, const FtgpVehicle& v, const CarCore* st, LidarFrame* fr, int slot)
+// LiDAR frame of a car at its current pose (lidar_car() of the oracle: centre, heading, binary32 pixel coordinates).
+// Returns whether every ray of this car is KNOWN to start on the image: the car races, and its LiDAR centre is finite and at
+// least edge_margin (ring radius in pixels + 2) away from every image edge.  When that holds for all cars of the workgroup the
+// sweep initialises its rays without the on-image test (ftgp_ray_init, assume_inside).
+__device__ __forceinline__ bool frame_write(const DeviceParams& P, const FtgpVehicle& v, const CarCore* st, LidarFrame* fr, int slot)
 {
     const double qw = st->qw, qz = st->qz;
     const double ch = 1.0 - 2.0 * (qz * qz), sh = 2.0 * (qw * qz);
     const double lcx = st->x + (ch * v.lidar_x - sh * v.lidar_y);
     const double lcy = st->y + (sh * v.lidar_x + ch * v.lidar_y);
     const int finished = st->finished;
-    fr->u0 = finished ? -INFINITY : (float)((lcx - P.origin_x) * P.inv_px_x);     // -inf: rangefinders switched off (see lidar_pool)
-    fr->v0 = (float)((P.origin_y - lcy) * P.inv_px_y);
+    const float u0 = (float)((lcx - P.origin_x) * P.inv_px_x), v0 = (float)((P.origin_y - lcy) * P.inv_px_y);
+    fr->u0 = finished ? -INFINITY : u0;                       // -inf: rangefinders switched off (see lidar_pool)
+    fr->v0 = v0;
     fr->chf = (float)ch; fr->shf = (float)sh;
     fr->lcx = lcx; fr->lcy = lcy;
     fr->x = st->x; fr->y = st->y; fr->qw = qw; fr->qz = qz;
@@ -587,6 +614,8 @@ __device__ __forceinline__ void frame_write(const DeviceParams& P, const FtgpVeh
         fr->slot0 = slot - slot % P.cars_per_env;
         fr->fx = (float)st->x; fr->fy = (float)st->y;
     }
+    const float m = P.edge_margin;
+    return !finished && u0 >= m && u0 <= (float)P.width - m && v0 >= m && v0 <= (float)P.height - m;      // false for a NaN
 }
 
 // K1 + K3 for every car of the workgroup by ONE wave, four lanes per car (lane = 4 * car + r).
@@ -599,7 +628,7 @@ __device__ __forceinline__ void frame_write(const DeviceParams& P, const FtgpVeh
 //       followed by the head of the next loop iteration.
 // Then the LiDAR frames of the next step are written.
 template <bool MULTI>
-__device__ __forceinline__ void dynamics_lanes(const DeviceParams& P, const Lds& L, LidarFrame* next_frames, int ncars_here, int ci0)
+__device__ __forceinline__ void dynamics_lanes(const DeviceParams& P, const Lds& L, LidarFrame* next_frames, int* unsafe_next, int ncars_here, int ci0)
 {
     const int lane = lane_here();
     const int c = lane >> 2, r = lane & 3;
@@ -735,7 +764,10 @@ __device__ __forceinline__ void dynamics_lanes(const DeviceParams& P, const Lds&
     }
     wave_lds_sync();
     // the LiDAR frames of the next step (its sweep starts after the workgroup barrier that ends this step)
-    if (on && r == 0) frame_write(P, v, st, next_frames + c, c);
+    bool safe = true;
+    if (on && r == 0) safe = frame_write(P, v, st, next_frames + c, c);
+    const bool any_unsafe = __any(!safe);
+    if (lane == 0) *unsafe_next = any_unsafe;
 }
 
 // Inclusive prefix sum over the 64 lanes of a wave with data-parallel-primitive moves (no LDS round trips): three shifts
@@ -934,7 +966,13 @@ __global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(cons
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = __builtin_amdgcn_readfirstlane(blockDim.x >> 6);
 #ifdef FTGP_STAMPS
-    if (threadIdx.x == 0 && blockIdx.x < 8192) ftgp_wg_times[blockIdx.x][0] = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0 && blockIdx.x < 8192) {
+        ftgp_wg_times[blockIdx.x][0] = __builtin_amdgcn_s_memrealtime();
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        ftgp_wg_times[blockIdx.x][2] = hw; ftgp_wg_times[blockIdx.x][3] = xcc;
+    }
 #endif
     // the parameter block itself goes to LDS: later reads come from there, not from ~70 pinned SGPRs
     stage16(lds + Pg->off_params, Pg, Pg->off_veh - Pg->off_params);
@@ -943,11 +981,13 @@ __global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(cons
     stage16(lds + Pg->off_ray, Pg->ray_dir, Pg->off_cars - Pg->off_ray);
     if (policy == FTGP_POLICY_NIDC || policy == FTGP_POLICY_FAST)
         stage16(lds + Pg->off_cover, Pg->cover_thr + (policy == FTGP_POLICY_FAST ? Pg->cover_kmax + 1 : 0), Pg->lds_bytes - Pg->off_cover);
+    if (threadIdx.x < 8) reinterpret_cast<int*>(lds + Pg->off_pool)[threadIdx.x] = 0;
     __syncthreads();
     const LdsOffsets off = lds_offsets(P0);
     const int cpb = sgpr(P0.cars_per_block);
     const int ci0 = (int)blockIdx.x * cpb;
     const int ncars_here = min(cpb, sgpr(P0.n_cars) - ci0);
+    const bool second_half = (((int)blockIdx.x / max(1, sgpr(P0.n_cu))) & 1) != 0;      // see sweep_priority(): workgroups b and b + n_cu share a CU in the first dispatch wave
     const bool need_scan = (policy == FTGP_POLICY_NIDC || policy == FTGP_POLICY_FAST);
     {
     const DeviceParams& P = P0;
@@ -965,9 +1005,8 @@ __global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(cons
             for (int j = eighth + lane; j < R - eighth; j += FTGP_WAVE) row[scan_window_first(eighth) + j - eighth] = my_ranges[j];
         }
         wave_lds_sync();
-        if (lane == 0) frame_write(P, L.veh->v, L.cars + c, L.frame + c, c);
+        if (lane == 0 && !frame_write(P, L.veh->v, L.cars + c, L.frame + c, c)) atomicOr(L.pool + 4, 1);
     }
-    if (threadIdx.x < 4) L.pool[threadIdx.x] = 0;
     }
     __syncthreads();
 
@@ -1010,7 +1049,7 @@ __global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(cons
             if (n == ncars_here - 1) {            // every driver of the workgroup has delivered its controls
                 if (lane == 0) { L.pool[par ^ 1] = 0; L.pool[2 + (par ^ 1)] = 0; }     // the next step's counters (idle during this step)
 #ifndef FTGP_ABLATE_K1
-                dynamics_lanes<MULTI>(P, L, next_frames, ncars_here, ci0);
+                dynamics_lanes<MULTI>(P, L, next_frames, L.pool + 4 + (par ^ 1), ncars_here, ci0);
 #endif
                 STAMP(t2); STAMP_ADD(2, t2 - t1); STAMP_ADD(7, 1);
             }
@@ -1020,7 +1059,7 @@ __global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(cons
 #endif
         STAMP(t3);
 #ifndef FTGP_ABLATE_K2
-        lidar_pool<MULTI>(P, L, frames, scan_now, L.pool + par, ncars_here, ci0, need_scan STAMP_PASS);
+        lidar_pool<MULTI>(P, L, frames, scan_now, L.pool + par, ncars_here, ci0, need_scan, second_half STAMP_PASS);
 #endif
         STAMP(t4);
         __syncthreads();

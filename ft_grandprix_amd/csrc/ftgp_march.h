@@ -123,22 +123,27 @@ FTGP_HD void ftgp_ray_park(FtgpRay& r, float result)
 }
 
 // fstride = W + 2 (cells per plane row); plane256 = bytes per sector plane / 256 (planes are padded to a multiple of 256 B);
-// ivx, ivy = |1 / du|, |1 / dv| correctly rounded (IEEE division; +inf where the direction is 0: that axis is never stepped)
-FTGP_HD void ftgp_ray_init(FtgpRay& r, float pu, float pv, float du, float dv, float ivx, float ivy, int W, int H, int fstride, uint32_t plane256)
+// ivx, ivy = |1 / du|, |1 / dv| correctly rounded (IEEE division; +inf where the direction is 0: that axis is never stepped).
+// assume_inside (a compile-time constant at every call site): the caller guarantees that (pu, pv) is finite and lies on the
+// image -- the step kernel does when every LiDAR centre of the workgroup is a ring radius plus two pixels away from the image
+// edge (frame_write) -- so the test, and the selects that park an off-image ray, are not needed.
+FTGP_HD void ftgp_ray_init(FtgpRay& r, float pu, float pv, float du, float dv, float ivx, float ivy, int W, int H, int fstride, uint32_t plane256,
+                           bool assume_inside = false)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     int ix0, iy0;                                             // floor and convert in one instruction; the conversion saturates
     asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ix0) : "v"(pu));
     asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(iy0) : "v"(pv));
-    const bool inside = !__builtin_isunordered(pu, pv) && (unsigned)ix0 < (unsigned)W && (unsigned)iy0 < (unsigned)H;   // a NaN converts to 0: test it
+    const bool inside = assume_inside || (!__builtin_isunordered(pu, pv) && (unsigned)ix0 < (unsigned)W && (unsigned)iy0 < (unsigned)H);   // a NaN converts to 0: test it
 #else
     const float fx = floorf(pu), fy = floorf(pv);
-    const bool inside = fx >= 0.0f && fx < (float)W && fy >= 0.0f && fy < (float)H;
+    const bool inside = assume_inside || (fx >= 0.0f && fx < (float)W && fy >= 0.0f && fy < (float)H);
     const int ix0 = (int)fx, iy0 = (int)fy;
 #endif
     // Mirrors, slope slice and offsets come out of sign bits with adds, shifts and logic (2-cycle instructions on gfx950)
     // rather than compares and selects (4 each).  A direction component of -0 mirrors its axis too: harmless, the ray never
-    // steps along it.
+    // steps along it.  (The dominant axis stays a compare and two selects: fminf / fmaxf bring canonicalising v_max x, x, x
+    // along, and integer min / max on the bit patterns cost what the selects cost.)
     const uint32_t bu = ftgp_bits(du), bv = ftgp_bits(dv);
     const int mxm = (int)bu >> 31, mym = (int)bv >> 31;       // 0 / -1
     const float adu = fabsf(du), adv = fabsf(dv);
@@ -147,7 +152,8 @@ FTGP_HD void ftgp_ray_init(FtgpRay& r, float pu, float pv, float du, float dv, f
     r.pvm = ftgp_float(ftgp_bits(pv) ^ (bv & 0x80000000u));
     r.dum = adu; r.dvm = adv;
     r.ivx = ivx; r.ivy = ivy;
-    r.s = 0.0f; r.result = -1.0f;
+    r.s = 0.0f;
+    if (!assume_inside) r.result = -1.0f;
     uint32_t sector = ((uint32_t)mxm & 1u) | ((uint32_t)mym & 2u) | (ydom ? 4u : 0u);
     {   // slope slice: the number of k in 1 .. NS - 1 with NS * minor > k * major; "a > b" as the sign of the rounded b - a
         // (a rounded difference has the sign of the exact one, and equal operands give +0)
@@ -168,6 +174,22 @@ FTGP_HD void ftgp_ray_init(FtgpRay& r, float pu, float pv, float du, float dv, f
 #endif
     r.offC = (int)(plane << 8) + (fstride + 2) + (mxm + mxm) + hy;
     if (!inside) { r.offC = 0; r.ax = r.ay = 0; }             // starts off the image: every cell maps to ring cell (0, 0) of plane 0, result stays -1
+}
+
+// The on-image test of ftgp_ray_init for a caller that initialised with assume_inside although it could not promise it:
+// a ray whose origin is off the image (or not a number) is parked exactly as ftgp_ray_init would have parked it.
+FTGP_HD void ftgp_ray_park_if_outside(FtgpRay& r, float pu, float pv, int W, int H)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    int ix0, iy0;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ix0) : "v"(pu));
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(iy0) : "v"(pv));
+    const bool inside = !__builtin_isunordered(pu, pv) && (unsigned)ix0 < (unsigned)W && (unsigned)iy0 < (unsigned)H;
+#else
+    const float fx = floorf(pu), fy = floorf(pv);
+    const bool inside = fx >= 0.0f && fx < (float)W && fy >= 0.0f && fy < (float)H;
+#endif
+    if (!inside) { r.offC = 0; r.ax = r.ay = 0; }
 }
 
 FTGP_HD int ftgp_ray_offset(const FtgpRay& r)

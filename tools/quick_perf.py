@@ -16,5 +16,10 @@ for path in libs:
             e.rollout(policy, 100); e.last_kernel_ms(); best = 1e9
             for _ in range(3):
                 e.rollout(policy, steps); best = min(best, e.last_kernel_ms())
-        out.append(f"{name}/{policy}/{envs}x{cars}: {best * 1e3 / steps:7.2f} us/step = {envs * steps / best / 1e3:6.2f} M env-steps/s")
+            short = 1e9
+            if os.environ.get("QUICK_SHORT"):          # the driver's bench shape: 20 steps per launch
+                for _ in range(6):
+                    e.rollout(policy, 20); short = min(short, e.last_kernel_ms())
+        out.append(f"{name}/{policy}/{envs}x{cars}: {best * 1e3 / steps:7.2f} us/step = {envs * steps / best / 1e3:6.2f} M env-steps/s"
+                   + (f" [20-step launch {short * 1e3 / 20:6.2f} us/step]" if short < 1e9 else ""))
     print(os.path.basename(path), " | ".join(out), flush=True)

@@ -65,6 +65,7 @@ int main(int argc, char** argv)
     // bound for "sort by the previous step's counts"); SORTED=2: ascending
     const int sorted_mode = getenv("SORTED") ? atoi(getenv("SORTED")) : 0;
     std::vector<std::vector<int>> perm(n_cars);
+    std::vector<long> mean_count(R, 0);
     if (sorted_mode) {
         for (int c = 0; c < n_cars; ++c) {
             std::vector<std::pair<int, int>> key(R);
@@ -86,7 +87,11 @@ int main(int argc, char** argv)
                 }
                 // SORTED=1 by count (descending), 2 ascending, 3 by range (descending, quantised to 1/8 world unit)
                 const int rq = (int)(fabsf(r.s) * 8.0f);
-                key[j] = { sorted_mode == 1 ? -n : sorted_mode == 3 ? -rq : n, j };
+                // SORTED=4: a static order, no measurement: rays along the car's axis (front and rear) first, sideways rays last
+                const int al = (int)(1000.0 * fabs(cos(2.0 * M_PI * j / R)));
+                // SORTED=5: static, by the mean iteration count of that ray index over all cars (filled below)
+                key[j] = { sorted_mode == 1 ? -n : sorted_mode == 3 ? -rq : sorted_mode == 4 ? -al : n, j };
+                if (sorted_mode == 5) { static std::vector<long> acc; if ((int)acc.size() != R) acc.assign(R, 0); acc[j] += n; key[j] = { 0, j }; if (c == n_cars - 1) { for (int q = 0; q < R; ++q) mean_count[q] = acc[q]; } }
             }
             perm[c].resize(R);
             const int BS = getenv("BLOCK") ? atoi(getenv("BLOCK")) : 1;
@@ -100,6 +105,11 @@ int main(int argc, char** argv)
                 for (int j = 0; j < R; ++j) perm[c][j] = key[j].second;
             }
         }
+    }
+    if (sorted_mode == 5) {         // one order for all cars
+        std::vector<std::pair<long, int>> k5(R); for (int j = 0; j < R; ++j) k5[j] = { -mean_count[j], j };
+        std::stable_sort(k5.begin(), k5.end());
+        for (int c = 0; c < n_cars; ++c) for (int j = 0; j < R; ++j) perm[c][j] = k5[j].second;
     }
     struct Lane { FtgpRay r; int g; bool done; };
     for (int c0 = 0; c0 < n_cars; c0 += cpb) {
@@ -165,6 +175,7 @@ int main(int argc, char** argv)
             }
         }
         max_wave_iters_sum += *std::max_element(witers.begin(), witers.end());
+        if (getenv("DUMPWG")) { long tot = 0; for (int x : witers) tot += x; printf("WG %d sum-wave-iters %ld max-wave-iters %d\n", c0 / cpb, tot, *std::max_element(witers.begin(), witers.end())); }
     }
     const double nsteps = (double)n_cars;
     printf("R %d cpb %d wpb %d refill %d eps 2^-%d: per car-step: wave-iters %.1f  refills %.1f  fix-branches %.1f  useful lane-iters %.0f (util %.2f)  iters/ray %.2f  "
