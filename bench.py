@@ -111,8 +111,10 @@ def cpu_baseline(track, n_rays, policy, cars, seed, budget_s=14.0):
                       + f" -- oracle/ftgp_oracle.c (the CPU restatement, OpenMP over envs); host has {host_cpus} logical CPUs, this process may use {share}"}
 
 
-def launch_ranks(n, argv):
-    """No launcher set WORLD_SIZE: start the N ranks ourselves (one child per GPU) and return the worst exit code."""
+def launch_ranks(n, argv, script=None, poll_s=0.2):
+    """No launcher set WORLD_SIZE: start the N ranks ourselves (one child per GPU).  Returns 0 only if every rank exits 0; as soon
+    as one rank fails the others are stopped (they would wait for it in the rendezvous until their timeout) and its code is
+    returned."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -120,16 +122,28 @@ def launch_ranks(n, argv):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    FTGP_JOB_TOKEN=f"bench-{os.getpid()}")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
-    rcs = []
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(script or __file__)] + argv, env=env))
+    worst = 0
     try:
-        for p in procs:
-            rcs.append(p.wait())
+        while any(p.poll() is None for p in procs):
+            bad = [p.returncode for p in procs if p.poll() not in (None, 0)]
+            if bad:
+                worst = max(abs(rc) for rc in bad)
+                break
+            time.sleep(poll_s)
+        bad = [p.returncode for p in procs if p.poll() not in (None, 0)]
+        if bad:
+            worst = max(worst, max(abs(rc) for rc in bad))
     finally:
         for p in procs:
             if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
                 p.kill()
-    return max(abs(rc) for rc in rcs)
+    return worst
 
 
 def main():

@@ -578,3 +578,22 @@ def test_config2_and_config5_full_size_properties(product, oracle):
             np.testing.assert_allclose(g.pose()[:n], o.pose(), rtol=0, atol=TOL)
             m = g.metrics_local()
             assert m[0] == kw["n_envs"] * steps and m[1] == g.n_cars
+
+
+def test_bench_two_ranks_host_gather():
+    """`bench.py --gpus 2` with no launcher: it starts its own two ranks (both on this box's one GPU: a rehearsal of the N > 1
+    plumbing -- rendezvous, env shards, barrier, max-over-ranks timing -- with the metrics gathered over the host instead of
+    RCCL, which cannot form a two-rank communicator on one device), and rank 0 prints ONE JSON line."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["FTGP_BENCH_COLLECTIVE"] = "host"
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--envs-per-gpu", "256"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["scaling"] == "weak" and "cpu_baseline" not in d
+    assert d["metrics_allgather"]["ranks"] == 2 and d["metrics_allgather"]["sum_steps"] == 2 * 256 * (2 + 5)
+    assert d["value"] == pytest.approx(2 * 256 * 5 / (d["ms_per_step"] * 5e-3), rel=1e-6)

@@ -188,3 +188,39 @@ def test_rendezvous_survives_stray_and_short_clients():
     for c in strays:
         c.close()
     r0.close(); r1.close()
+
+
+# ---------------------------------------------------------------- bench.py --gpus N: the self-launcher
+def test_bench_launcher_stops_the_job_when_one_rank_fails(tmp_path):
+    """One rank dies, the other would wait for it (rendezvous, RCCL bootstrap): the launcher must stop the survivor and exit
+    non-zero with the failing rank's code -- promptly, not after the survivor's timeout."""
+    import bench
+    child = tmp_path / "child.py"
+    child.write_text("import os, sys, time\n"
+                     "r = int(os.environ['RANK'])\n"
+                     "assert os.environ['WORLD_SIZE'] == '2' and os.environ['MASTER_ADDR'] == '127.0.0.1' and os.environ['LOCAL_RANK'] == str(r)\n"
+                     "open(sys.argv[1] + f'/started{r}', 'w').close()\n"
+                     "if r == 1:\n    sys.exit(5)\n"
+                     "time.sleep(120)\nopen(sys.argv[1] + '/survived', 'w').close()\n")
+    t0 = time.time()
+    rc = bench.launch_ranks(2, [str(tmp_path)], script=str(child))
+    assert rc == 5 and time.time() - t0 < 30
+    assert (tmp_path / "started0").exists() and (tmp_path / "started1").exists() and not (tmp_path / "survived").exists()
+    ok = tmp_path / "ok.py"
+    ok.write_text("import sys\nsys.exit(0)\n")
+    assert bench.launch_ranks(3, [], script=str(ok)) == 0
+
+
+def test_bench_gpus_2_without_a_gpu_fails_loudly():
+    """`python bench.py --gpus 2` with no launcher in the environment starts its own two ranks; with no HIP device each of them
+    refuses to run (no CPU fallback) and the parent's exit code says so."""
+    import subprocess
+    from ft_grandprix_amd import capi
+    if capi.load().fn("device_count")() >= 1:
+        pytest.skip("a GPU is present: the happy path is tests/test_gpu_parity.py::test_bench_two_ranks_host_gather")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["FTGP_BENCH_COLLECTIVE"] = "host"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--envs-per-gpu", "16"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0
+    assert p.stderr.count("needs a HIP device") >= 1 and p.stdout.strip() == ""
