@@ -75,7 +75,8 @@ struct FtgpEnv {
     double* d_path = nullptr; double* d_spawn = nullptr; float* d_ray = nullptr; float* d_cover = nullptr; void* d_veh = nullptr; DeviceParams* d_params = nullptr;
     CarState* d_cars = nullptr; float* d_ranges = nullptr; int64_t* d_steps = nullptr;
     uint8_t* d_env_mask = nullptr; uint8_t* d_car_mask = nullptr; double* d_ctrl = nullptr; double* d_pose = nullptr;
-    double* d_metrics = nullptr; double* d_gather = nullptr;
+    double* d_metrics = nullptr; double* d_gather = nullptr; double* d_wg_metrics = nullptr; unsigned int* d_wg_ticket = nullptr;
+    bool launch_metrics_valid = false;   // the record the last step launch left in d_metrics / h_metrics still describes the state (no reset / set_pose / ... since)
     double* h_metrics = nullptr;      // pinned landing buffer of the metrics record(s): the copy back is one small DMA, not a staged one
     int h_metrics_ranks = 0;
     double* h_metrics_dev = nullptr;  // the same buffer as the device sees it: a single-rank record is written straight into it
@@ -218,6 +219,7 @@ int launch_steps(FtgpEnv* e, int policy, int n_steps)
         if (e->multi) hipLaunchKernelGGL((ftgp_step_kernel<true>), grid, block, lds, e->stream, e->d_params, policy, n_steps);
         else          hipLaunchKernelGGL((ftgp_step_kernel<false>), grid, block, lds, e->stream, e->d_params, policy, n_steps);
         HIP_TRY(hipGetLastError());
+        e->launch_metrics_valid = e->d_wg_metrics != nullptr;
     }
     HIP_TRY(hipEventRecord(e->ev_stop, e->stream));
     e->timed = true;
@@ -321,7 +323,7 @@ int ftgp_destroy(FtgpEnv* e)
     if (e->side) (void)hipStreamSynchronize(e->side);
     if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
     void* bufs[] = { e->d_field, e->d_bits, e->d_nearbits, e->d_cover, e->d_params, e->d_veh, e->d_path, e->d_spawn, e->d_ray, e->d_cars, e->d_ranges,
-                     e->d_steps, e->d_env_mask, e->d_car_mask, e->d_ctrl, e->d_pose, e->d_metrics, e->d_gather, e->d_prog, e->d_core };
+                     e->d_steps, e->d_env_mask, e->d_car_mask, e->d_ctrl, e->d_pose, e->d_metrics, e->d_gather, e->d_prog, e->d_core, e->d_wg_metrics, e->d_wg_ticket };
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (e->h_metrics) (void)hipHostFree(e->h_metrics);
     if (e->ev_start) (void)hipEventDestroy(e->ev_start);
@@ -526,6 +528,13 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
     CREATE_TRY(hipMalloc(&e->d_metrics, sizeof(double) * FTGP_METRIC_DOUBLES));
     CREATE_TRY(hipHostMalloc(&e->h_metrics, sizeof(double) * FTGP_METRIC_DOUBLES, hipHostMallocMapped)); e->h_metrics_ranks = 1;
     CREATE_TRY(hipHostGetDevicePointer((void**)&e->h_metrics_dev, e->h_metrics, 0));
+    if (!getenv("FTGP_NO_FUSED_METRICS")) {          // (diagnostic switch: tests compare the fused record with ftgp_metrics_kernel's)
+        const size_t blocks = (n_cars + (size_t)P.cars_per_block - 1) / (size_t)P.cars_per_block;
+        CREATE_TRY(hipMalloc(&e->d_wg_metrics, sizeof(double) * FTGP_METRIC_DOUBLES * blocks));
+        CREATE_TRY(hipMalloc(&e->d_wg_ticket, sizeof(unsigned int)));
+        CREATE_TRY(hipMemsetAsync(e->d_wg_ticket, 0, sizeof(unsigned int), e->stream));
+        P.wg_metrics = e->d_wg_metrics; P.wg_ticket = e->d_wg_ticket; P.metrics_dev = e->d_metrics; P.metrics_host = e->h_metrics_dev;
+    }
     CREATE_TRY(hipMalloc(&e->d_prog, sizeof(int32_t) * FTGP_PROGRESS_INTS * n_cars));
     CREATE_TRY(hipMalloc(&e->d_core, sizeof(double) * kCoreDoubles * n_cars));
     CREATE_TRY(hipMemcpy(e->d_bits, tab.bits.data(), sz_bits, hipMemcpyHostToDevice));
@@ -559,7 +568,7 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
 int ftgp_reset(FtgpEnv* e, const uint8_t* mask)
 {
     if (!e) return fail(FTGP_ERR_ARG, "null handle%s");
-    e->rows_valid = false;
+    e->rows_valid = false; e->launch_metrics_valid = false;
     HIP_TRY(hipSetDevice(e->device));
     const uint8_t* dmask = nullptr;
     if (mask) {
@@ -651,7 +660,7 @@ int ftgp_get_pose(FtgpEnv* e, double* out)
 int ftgp_set_pose(FtgpEnv* e, const double* pose)
 {
     if (!e || !pose) return fail(FTGP_ERR_ARG, "null argument%s");
-    e->rows_valid = false;
+    e->rows_valid = false; e->launch_metrics_valid = false;
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipMemcpyAsync(e->d_pose, pose, sizeof(double) * FTGP_POSE_DOUBLES * (size_t)e->P.n_cars, hipMemcpyHostToDevice, e->stream));
     hipLaunchKernelGGL(ftgp_set_pose_kernel, dim3((e->P.n_cars + 255) / 256), dim3(256), 0, e->stream, e->P, e->d_pose);
@@ -684,7 +693,7 @@ int ftgp_policy_eval(FtgpEnv* e, int policy, const float* ranges, double* ctrl_o
 int ftgp_eval_progress(FtgpEnv* e)
 {
     if (!e) return fail(FTGP_ERR_ARG, "null handle%s");
-    e->rows_valid = false;
+    e->rows_valid = false; e->launch_metrics_valid = false;
     HIP_TRY(hipSetDevice(e->device));
     hipLaunchKernelGGL(ftgp_progress_kernel, dim3((e->P.n_cars + 63) / 64), dim3(64), 0, e->stream, e->P);
     HIP_TRY(hipGetLastError());
@@ -757,6 +766,11 @@ int ftgp_get_steps(FtgpEnv* e, int64_t* out)
 // the record of this GPU, reduced on the compute stream and written by the kernel straight into pinned host memory
 static int metrics_to_host(FtgpEnv* e, double* out)
 {
+    if (e->launch_metrics_valid) {       // the step kernel's last workgroup has written the record of this very state into pinned memory
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        memcpy(out, e->h_metrics, sizeof(double) * FTGP_METRIC_DOUBLES);
+        return 0;
+    }
     hipLaunchKernelGGL(ftgp_metrics_kernel, dim3(1), dim3(FTGP_METRIC_THREADS), 0, e->stream, e->P, e->h_metrics_dev);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(e->stream));
@@ -798,6 +812,12 @@ int ftgp_comm_init(FtgpEnv* e, const uint8_t id[128], int rank, int world_size)
         HIP_TRY(hipHostMalloc(&e->h_metrics, sizeof(double) * FTGP_METRIC_DOUBLES * (size_t)world_size, hipHostMallocMapped));
         HIP_TRY(hipHostGetDevicePointer((void**)&e->h_metrics_dev, e->h_metrics, 0));
         e->h_metrics_ranks = world_size;
+        if (e->P.metrics_host) {         // the step kernel's epilogue writes this rank's record there: tell it about the new buffer
+            e->P.metrics_host = e->h_metrics_dev;
+            HIP_TRY(hipStreamSynchronize(e->stream));
+            HIP_TRY(hipMemcpy(e->d_params, &e->P, sizeof(DeviceParams), hipMemcpyHostToDevice));
+            e->launch_metrics_valid = false;
+        }
     }
     return 0;
 }
@@ -808,8 +828,10 @@ int ftgp_metrics_allgather(FtgpEnv* e, double* out)
     HIP_TRY(hipSetDevice(e->device));
     // reduce on the compute stream (it reads the state the step kernel wrote), gather on the side stream
     if (!e->comm || e->world == 1) return metrics_to_host(e, out);
-    hipLaunchKernelGGL(ftgp_metrics_kernel, dim3(1), dim3(FTGP_METRIC_THREADS), 0, e->stream, e->P, e->d_metrics);
-    HIP_TRY(hipGetLastError());
+    if (!e->launch_metrics_valid) {      // otherwise d_metrics already holds this state's record (step kernel epilogue)
+        hipLaunchKernelGGL(ftgp_metrics_kernel, dim3(1), dim3(FTGP_METRIC_THREADS), 0, e->stream, e->P, e->d_metrics);
+        HIP_TRY(hipGetLastError());
+    }
     HIP_TRY(hipEventRecord(e->ev_metrics, e->stream));
     HIP_TRY(hipStreamWaitEvent(e->side, e->ev_metrics, 0));
     int r = g_rccl.AllGather(e->d_metrics, e->d_gather, FTGP_METRIC_DOUBLES, kNcclFloat64, e->comm, e->side);

@@ -74,6 +74,13 @@ struct DeviceParams {
     CarState* cars;
     float* ranges;                // [n_cars][ranges_stride]
     int64_t* steps;               // [n_envs]
+    // end-of-launch metrics (ftgp_step_kernel's epilogue): one FTGP_METRIC_DOUBLES record per workgroup, an arrival counter, and
+    // the two places the last workgroup to arrive writes the launch's record to (device memory for the RCCL all-gather, pinned
+    // host memory for the caller); null: the step kernel leaves the metrics to ftgp_metrics_kernel
+    double* wg_metrics;
+    unsigned int* wg_ticket;
+    double* metrics_dev;
+    double* metrics_host;
     FtgpVehicle veh;              // host-side copy (the step kernel reads the LDS image VehLds; from here on nothing is staged into LDS)
     double wheel_load[4];
 };

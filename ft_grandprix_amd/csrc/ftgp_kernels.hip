@@ -942,6 +942,82 @@ __device__ __forceinline__ void policy_apply(const DeviceParams& P, int policy, 
 }
 
 // =============================================================================================
+// End-of-launch metrics record (FTGP_METRIC_DOUBLES; the record ftgp_metrics_kernel computes from the state in HBM), folded into
+// the step kernel so that a launch needs no second kernel and no second synchronisation: every workgroup reduces its own cars
+// and publishes the partial record; the workgroup that arrives last adds the partials up.  The sums are integers, exact in
+// binary64 in any order, so the result is bit-identical to the separate kernel's.  Hand-off between workgroups in the counter
+// form of the CDNA guide with write-through stores: ONE lane stores its workgroup's record with agent-scope (sc1) stores, waits
+// for them and draws a ticket (relaxed agent-scope fetch_add); the workgroup that draws the last ticket takes an agent-scope
+// acquire fence, waits, passes a barrier and reads the records.  (A release fence per workgroup instead -- an L2 write-back
+// each -- cost 14 us per launch, as much as the separate kernel.)
+__device__ __forceinline__ double wave_sum_f64(double v)
+{
+    #pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_f64(v, m);
+    return v;
+}
+
+// called by ALL threads of the workgroup, after the state records have gone back to HBM; `scratch`: one int of LDS
+__device__ __forceinline__ void launch_metrics(const DeviceParams& P, const CarCore* cars_lds, const int64_t* steps_lds, int ncars_here, int ci0,
+                                               unsigned char* scratch)
+{
+    int* last_flag = reinterpret_cast<int*>(scratch);
+    const int lane = lane_id();
+    if (threadIdx.x < FTGP_WAVE) {                       // wave 0: one car per lane (a workgroup holds at most 16)
+        double v[7] = { 0, 0, 0, 0, 0, INFINITY, -INFINITY };      // steps, laps, absolute completion, finished, off track, min / max lap time
+        if (lane < ncars_here) {
+            const CarCore* a = cars_lds + lane;
+            const int ci = ci0 + lane;
+            const int lc = a->good_start ? a->completion : -(100 - a->completion);     // custom.py:132-143
+            if (ci % P.cars_per_env == 0) v[0] = (double)steps_lds[lane];
+            v[1] = a->laps; v[2] = a->laps * 100 + lc; v[3] = a->finished; v[4] = a->off_track;
+            const int n = a->n_times < FTGP_MAX_LAP_TIMES ? a->n_times : FTGP_MAX_LAP_TIMES;
+            const double* t = P.cars[ci].times;
+            for (int k = 0; k < n; ++k) { v[5] = fmin(v[5], t[k]); v[6] = fmax(v[6], t[k]); }
+        }
+        #pragma unroll
+        for (int q = 0; q < 5; ++q) v[q] = wave_sum_f64(v[q]);
+        #pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { v[5] = fmin(v[5], shfl_xor_f64(v[5], m)); v[6] = fmax(v[6], shfl_xor_f64(v[6], m)); }
+        if (lane == 0) {
+            // the one lane that publishes also counts: write-through (agent-scope) stores of the record, wait for them, then the ticket
+            double* mine = P.wg_metrics + (size_t)blockIdx.x * FTGP_METRIC_DOUBLES;
+            const double rec[FTGP_METRIC_DOUBLES] = { v[0], (double)ncars_here, v[1], v[2], v[3], v[4], v[5], v[6] };
+            #pragma unroll
+            for (int q = 0; q < FTGP_METRIC_DOUBLES; ++q) __hip_atomic_store(mine + q, rec[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned int ticket = __hip_atomic_fetch_add(P.wg_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *last_flag = ticket == gridDim.x - 1;
+        }
+    }
+    __syncthreads();
+    if (!*last_flag) return;                              // workgroup-uniform
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (threadIdx.x < FTGP_WAVE) {
+        double v[FTGP_METRIC_DOUBLES] = { 0, 0, 0, 0, 0, 0, INFINITY, -INFINITY };
+        for (unsigned int b = lane; b < gridDim.x; b += FTGP_WAVE) {
+            const double* r = P.wg_metrics + (size_t)b * FTGP_METRIC_DOUBLES;
+            #pragma unroll
+            for (int q = 0; q < 6; ++q) v[q] += r[q];
+            v[6] = fmin(v[6], r[6]); v[7] = fmax(v[7], r[7]);
+        }
+        #pragma unroll
+        for (int q = 0; q < 6; ++q) v[q] = wave_sum_f64(v[q]);
+        #pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { v[6] = fmin(v[6], shfl_xor_f64(v[6], m)); v[7] = fmax(v[7], shfl_xor_f64(v[7], m)); }
+        if (lane == 0) {
+            #pragma unroll
+            for (int q = 0; q < FTGP_METRIC_DOUBLES; ++q) { P.metrics_dev[q] = v[q]; P.metrics_host[q] = v[q]; }
+            __hip_atomic_store(P.wg_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the next launch counts from zero again
+        }
+    }
+}
+
+// =============================================================================================
 // The step kernel.  Per step and car, in the order of the reference loop (custom.py:1337-1426):
 //   driver(previous scan) -> ctrl -> [mj_step: sensors at the current pose, integrate] -> steps += 1 ->
 //   progress at the new pose (= the head of the next loop iteration).
@@ -1079,6 +1155,10 @@ __global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(cons
         if (lane < (int)(sizeof(CarCore) / 4))
             reinterpret_cast<uint32_t*>(static_cast<CarCore*>(&P.cars[ci]))[lane] = reinterpret_cast<const uint32_t*>(L.cars + c)[lane];
         if (lane == 0 && ci % P.cars_per_env == 0) P.steps[ci / P.cars_per_env] = L.steps[c];
+    }
+    if (P.wg_metrics) {                  // the scan windows are dead now: their first bytes serve as the reduction scratch
+        __syncthreads();
+        launch_metrics(P, L.cars, L.steps, ncars_here, ci0, lds + P.off_scan);
     }
 #ifdef FTGP_STAMPS
     __syncthreads();
@@ -1262,12 +1342,6 @@ __global__ void ftgp_box_field_kernel(const uint16_t* __restrict__ runx, const u
 // loads want to be in flight together); reduction inside each wave by shuffles, then across the 16 waves through LDS.  The
 // sums are integers, exact in binary64 in any order.
 #define FTGP_METRIC_THREADS 1024
-__device__ __forceinline__ double wave_sum_f64(double v)
-{
-    #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_f64(v, m);
-    return v;
-}
 __global__ void __launch_bounds__(FTGP_METRIC_THREADS) ftgp_metrics_kernel(DeviceParams P, double* __restrict__ out)
 {
     __shared__ double part[7][FTGP_METRIC_THREADS / FTGP_WAVE];

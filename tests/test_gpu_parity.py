@@ -597,3 +597,36 @@ def test_bench_two_ranks_host_gather():
     assert d["n_gpus"] == 2 and d["steps"] == 5 and d["scaling"] == "weak" and "cpu_baseline" not in d
     assert d["metrics_allgather"]["ranks"] == 2 and d["metrics_allgather"]["sum_steps"] == 2 * 256 * (2 + 5)
     assert d["value"] == pytest.approx(2 * 256 * 5 / (d["ms_per_step"] * 5e-3), rel=1e-6)
+
+
+def test_launch_metrics_record_equals_the_metrics_kernel(product, oracle):
+    """The record the step kernel's last workgroup leaves behind (read without a second kernel) against ftgp_metrics_kernel on the
+    same state (a handle created with the diagnostic switch FTGP_NO_FUSED_METRICS) and against the oracle, through lap events,
+    ragged workgroups and calls that invalidate the cached record."""
+    import os
+    t = load_track("circle")
+    kw = dict(n_envs=37, n_rays=90, lap_target=1, spawn_mode=1, seed=7)
+    g = capi.Env(product, t, **kw)
+    os.environ["FTGP_NO_FUSED_METRICS"] = "1"
+    try:
+        k = capi.Env(product, t, **kw)
+    finally:
+        del os.environ["FTGP_NO_FUSED_METRICS"]
+    o = capi.Env(oracle, t, **kw)
+    oracle.dll.oracle_set_threads(o.h, 8)
+    with g, k, o:
+        for n in (1, 250, 9000, 10000):
+            for e in (g, k, o):
+                e.rollout("nidc", n)
+            np.testing.assert_array_equal(g.metrics_local(), k.metrics_local())
+            np.testing.assert_array_equal(g.metrics_local(), o.metrics_local())
+            np.testing.assert_array_equal(g.metrics_allgather()[0], k.metrics_local())
+        assert g.metrics_local()[4] > 0 and np.isfinite(g.metrics_local()[6])          # some cars finished: lap times in the record
+        mask = np.zeros(37, dtype=np.uint8); mask[::2] = 1
+        for e in (g, k, o):
+            e.reset(mask)                                                                # the cached record no longer describes the state
+        np.testing.assert_array_equal(g.metrics_local(), k.metrics_local())
+        np.testing.assert_array_equal(g.metrics_local(), o.metrics_local())
+        for e in (g, k, o):
+            e.step(3)
+        np.testing.assert_array_equal(g.metrics_local(), o.metrics_local())
