@@ -65,6 +65,20 @@ def committed_counters(name, n_envs, n_rays, cars, policy):
     return None
 
 
+def baseline_config(args, world):
+    """Which BASELINE.json config the flags amount to."""
+    key = (args.envs_per_gpu, args.cars, args.track, args.rays, args.policy)
+    if key == (4096, 1, "track", 1080, "fast"):
+        return "BASELINE.json configs[2], the headline" if world == 1 else f"BASELINE.json configs[2] per GPU, x{world} GPUs"
+    if key == (4096, 1, "track", 1080, "random"):
+        return "BASELINE.json configs[3]: 32768 envs over 8 GPUs" if world == 8 else f"BASELINE.json configs[3] per-GPU shard, x{world} GPUs"
+    if key == (1024, 1, "circle", 1080, "nidc"):
+        return "BASELINE.json configs[1]"
+    if key[:4] == (4096, 4, "track", 1080):
+        return "BASELINE.json configs[4]: 4-car worlds with inter-vehicle rays"
+    return "not a BASELINE.json config"
+
+
 def cpu_share():
     """CPUs this process may actually use: the affinity mask, cut by a cgroup CPU quota if there is one."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -281,7 +295,7 @@ def main():
             "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32 rays + f64 state", "data": "synthetic",
             "config": {"workload": f"{args.envs_per_gpu} envs/GPU x {args.cars} car(s), {args.track} track blob, "
-                                   f"{args.rays}-ray LiDAR, {args.policy} driver on device (BASELINE.json configs[2])",
+                                   f"{args.rays}-ray LiDAR, {args.policy} driver on device ({baseline_config(args, world)})",
                        "envs_per_gpu": args.envs_per_gpu, "n_rays": args.rays, "cars_per_env": args.cars,
                        "policy": args.policy, "steps_per_launch": args.steps, "parallelism": f"env-shard x{world}"},
             "roofline": roof,

@@ -1,6 +1,7 @@
 // Per-car cost of one LiDAR sweep (tools only): total march iterations of the car's n_rays rays with the SHIPPED march
 // (ftgp_march.h), for every pose of a poses file.  Formats as tools/sweep_model.cpp.
-//   build: g++ -O2 -std=c++17 -I. tools/car_cost.cpp -o /tmp/car_cost      run: /tmp/car_cost track.raw poses.bin n_rays > costs.txt
+//   build: g++ -O2 -std=c++17 -I. tools/car_cost.cpp -o /tmp/car_cost      run: /tmp/car_cost track.raw poses.bin n_rays [counts.u8] > costs.txt
+//   counts.u8: n_cars x n_rays bytes, the iteration count of every ray (tools/order_probe.py sorts the pool by them)
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -41,6 +42,8 @@ int main(int argc, char** argv)
     std::vector<float> bx(R), by(R);
     for (int j = 0; j < R; ++j) { const double phi = ((360.0 / R) * j - 90.0) * (M_PI / 180.0); bx[j] = (float)sin(phi); by[j] = (float)(-cos(phi)); }
     const float isx = (float)(1.0 / ph[1]), isy = (float)(1.0 / ph[2]), r0 = 0.03f;
+    FILE* fc = argc > 4 ? fopen(argv[4], "wb") : nullptr;
+    std::vector<uint8_t> cnt(R);
     for (int c = 0; c < n_cars; ++c) {
         const double* p = &pose[(size_t)c * 4];
         const double ch = 1.0 - 2.0 * (p[3] * p[3]), sh = 2.0 * (p[2] * p[3]);
@@ -52,6 +55,7 @@ int main(int argc, char** argv)
             const float dxw = fmaf(chf, bx[j], -(shf * by[j])), dyw = fmaf(shf, bx[j], chf * by[j]);
             const float du = dxw * isx, dv = -(dyw * isy);
             FtgpRay r; ftgp_ray_init(r, fmaf(du, -r0, u0), fmaf(dv, -r0, v0), du, dv, fabsf(1.0f / du), fabsf(1.0f / dv), W, H, fstride, plane256);
+            int mine = 0;
             for (int n = 0; n < 100000; ++n) {
                 const size_t idx = (uint32_t)ftgp_ray_offset(r) >> 1;
                 if (!have[idx]) {
@@ -61,12 +65,15 @@ int main(int argc, char** argv)
                 }
                 FtgpStep st; const bool near = ftgp_ray_step(r, field[idx], eps, st);
                 ftgp_ray_commit(r, st, near ? ftgp_ray_fix(r, st) : st.t);
-                ++iters;
+                ++iters; ++mine;
                 if (!st.live) break;
             }
             sumr += fabsf(r.s);
+            cnt[j] = (uint8_t)(mine > 255 ? 255 : mine);
         }
+        if (fc) fwrite(cnt.data(), 1, cnt.size(), fc);
         printf("%ld %.3f\n", iters, sumr);
     }
+    if (fc) fclose(fc);
     return 0;
 }

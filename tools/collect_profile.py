@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """One GPU-box visit that produces the judged evidence for a build (run it through gpurun, then copy gpurun_out/profile/* to
-profiles/roundN/):   python3 tools/collect_profile.py [steps]
+profiles/roundN/):   python3 tools/collect_profile.py [steps] [envs] [policy] [cars] [track] [tag]   (default: the headline; a tag
+other than "latest" names the files sq_<tag>.json, ... and leaves the files bench.py reads alone)
   bench.json                       python bench.py (the driver's line, with cpu_baseline)
   kernel_stats.csv                 rocprofv3 --kernel-trace --stats of the same bench command (average duration per kernel)
   sq_latest.json                   SQ counters of the step kernel, three --pmc passes (own runs, kernel-trace only)
@@ -13,7 +14,12 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 os.chdir(ROOT)
 OUT = "gpurun_out/profile"
 STEPS = int(sys.argv[1]) if len(sys.argv) > 1 else 500
-ENVS, RAYS, POLICY, CARS = 4096, 1080, "fast", 1
+ENVS = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+POLICY = sys.argv[3] if len(sys.argv) > 3 else "fast"
+CARS = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+TRACK = sys.argv[5] if len(sys.argv) > 5 else "track"
+TAG = sys.argv[6] if len(sys.argv) > 6 else "latest"
+RAYS = 1080
 os.environ.setdefault("TMPDIR", "/tmp")
 
 
@@ -37,7 +43,7 @@ def pmc(tag, counters):
     d = f"{OUT}/raw_{tag}"
     shutil.rmtree(d, ignore_errors=True)
     run(["rocprofv3", "--kernel-trace", "--pmc", *counters, "--output-format", "csv", "-d", d, "--",
-         "python3", "tools/prof_case.py", str(ENVS), str(RAYS), POLICY, str(STEPS)], f"{OUT}/raw_{tag}.log")
+         "python3", "tools/prof_case.py", str(ENVS), str(RAYS), POLICY, str(STEPS), str(CARS), TRACK], f"{OUT}/raw_{tag}.log")
     rows = [r for r in csv.DictReader(open(glob.glob(f"{d}/**/*counter_collection.csv", recursive=True)[0])) if "ftgp_step_kernel" in r["Kernel_Name"]]
     last = max(int(r["Dispatch_Id"]) for r in rows)
     c, meta = {}, {}
@@ -52,7 +58,7 @@ def pmc(tag, counters):
 
 
 os.makedirs(OUT, exist_ok=True)
-base = {"config": f"{ENVS} envs x {RAYS} rays, {POLICY}, {STEPS} steps per launch", "steps": STEPS, "n_envs": ENVS, "n_rays": RAYS, "cars": CARS,
+base = {"config": f"{ENVS} envs x {CARS} car(s) x {RAYS} rays, {TRACK}, {POLICY}, {STEPS} steps per launch", "track": TRACK, "steps": STEPS, "n_envs": ENVS, "n_rays": RAYS, "cars": CARS,
         "policy": POLICY, "kernel_source_sha": sha()}
 
 # 1. SQ counters (8 slots per pass)
@@ -69,7 +75,7 @@ sq["derived"] = {"valu_insts_per_car_step": c["SQ_INSTS_VALU"] / n, "salu_insts_
                  "valu_busy_frac": c["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024 * c["GRBM_GUI_ACTIVE"] / 8.0),
                  "wait_any_frac_of_wave_cycles": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], "wait_inst_frac_of_wave_cycles": c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"],
                  "shader_clock_ghz": c["GRBM_GUI_ACTIVE"] / 8.0 / (sq["kernel_ms"] * 1e6)}
-json.dump(sq, open(f"{OUT}/sq_latest.json", "w"), indent=1)
+json.dump(sq, open(f"{OUT}/sq_{TAG}.json", "w"), indent=1)
 
 # 2. HBM traffic (separate passes; FETCH_SIZE costs 3 TCC slots, WRITE_SIZE 2)
 tr = dict(base)
@@ -81,21 +87,25 @@ tr["fetch_bytes_per_launch_x2"] = tr["FETCH_SIZE_raw_KB"] * 2048        # MI355X
 tr["traffic_bytes_per_launch"] = tr["write_bytes_per_launch"] + tr["fetch_bytes_per_launch_x2"]
 tr["traffic_bytes_per_env_step"] = tr["traffic_bytes_per_launch"] / (ENVS * STEPS)
 tr["write_bytes_per_env_step"] = tr["write_bytes_per_launch"] / (ENVS * STEPS)
-json.dump(tr, open(f"{OUT}/traffic_latest.json", "w"), indent=1)
+tr["algorithmic_bytes_per_env_step"] = CARS * (4 * RAYS + 832)
+json.dump(tr, open(f"{OUT}/traffic_{TAG}.json", "w"), indent=1)
 
 # 3. the bench line reads these two files: give it the ones of this very visit (same sources, so nothing is "stale")
-PROFILES = "profiles/round2"
-for name in ("sq_latest.json", "traffic_latest.json"):
+PROFILES = "profiles/round3"
+os.makedirs(PROFILES, exist_ok=True)
+for name in (f"sq_{TAG}.json", f"traffic_{TAG}.json"):
     shutil.copy(f"{OUT}/{name}", f"{PROFILES}/{name}")
 
 # 4. the bench line + kernel stats of the same command
-run(["python3", "bench.py", "--steps", str(STEPS), "--warmup", "50"], f"{OUT}/bench.log", 600)
-line = [l for l in open(f"{OUT}/bench.log").read().splitlines() if l.startswith("{")][-1]
-open(f"{OUT}/bench.json", "w").write(line + "\n")
+cfg = ["--envs-per-gpu", str(ENVS), "--policy", POLICY, "--cars", str(CARS), "--track", TRACK]
+SUFFIX = "" if TAG == "latest" else "_" + TAG
+run(["python3", "bench.py", "--steps", str(STEPS), "--warmup", "50", *cfg] + ([] if TAG == "latest" else ["--no-cpu-baseline"]), f"{OUT}/bench{SUFFIX}.log", 600)
+line = [l for l in open(f"{OUT}/bench{SUFFIX}.log").read().splitlines() if l.startswith("{")][-1]
+open(f"{OUT}/bench{SUFFIX}.json", "w").write(line + "\n")
 shutil.rmtree(f"{OUT}/raw_stats", ignore_errors=True)
 run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", f"{OUT}/raw_stats", "--",
-     "python3", "bench.py", "--steps", str(STEPS), "--warmup", "50", "--no-cpu-baseline"], f"{OUT}/raw_stats.log", 600)
-shutil.copy(glob.glob(f"{OUT}/raw_stats/**/*kernel_stats.csv", recursive=True)[0], f"{OUT}/kernel_stats.csv")
+     "python3", "bench.py", "--steps", str(STEPS), "--warmup", "50", "--no-cpu-baseline", *cfg], f"{OUT}/raw_stats.log", 600)
+shutil.copy(glob.glob(f"{OUT}/raw_stats/**/*kernel_stats.csv", recursive=True)[0], f"{OUT}/kernel_stats{SUFFIX}.csv")
 
 for d in glob.glob(f"{OUT}/raw_*"):
     if os.path.isdir(d):
