@@ -190,6 +190,7 @@ int lds_layout(DeviceParams& P, int cpb, int wpb)
     P.off_ray = o;    o += pad16(sizeof(float) * 2 * (size_t)P.n_rays);
     P.off_cars = o;   o += cpb * (int)sizeof(CarCore);
     P.off_frame = o;  o += 2 * cpb * (int)sizeof(LidarFrame);      // double-buffered by step parity
+    if (P.cars_per_env > 1) o += 2 * cpb * FTGP_PAIR_STRIDE * (int)sizeof(PairCull);   // env-mate records, right behind the frames
     P.off_steps = o;  o += pad16((size_t)cpb * sizeof(int64_t));
     P.off_scan = o;   o += 2 * cpb * P.win_floats * (int)sizeof(float);   // double-buffered by step parity
     P.off_list = o;   o += std::min(cpb, wpb) * FTGP_WAVE * (int)sizeof(int);                 // driver scratch: wave c runs the driver of car c

@@ -42,6 +42,14 @@ struct alignas(16) LidarFrame {
 };
 static_assert(sizeof(LidarFrame) == 80, "LidarFrame layout");
 
+// Multi-car envs: what a ray of car `me` needs to know about env-mate k to rule it out without looking at it.  B = mate's
+// origin - my LiDAR centre; every visible part of the mate lies within `cull` of its origin, so a ray of direction d can only
+// touch it if the mate sits in front and within `cull` of the ray's line, i.e. if  B . d >= sqrt(|B|^2 - cull^2) =: t.
+// t = +inf: never (myself, a finished car -- invisible, custom.py:1441-1466 -- or my own rangefinders are off);
+// t = -inf: always look (the mate is closer than 2 cull + ring radius, where the bound does not hold).
+struct alignas(16) PairCull { float bx, by, t, pad; };
+#define FTGP_PAIR_STRIDE 8              // FtgpConfig.cars_per_env <= 8
+
 struct DeviceParams {
     // sizes
     int32_t n_envs, cars_per_env, n_cars, n_rays;

@@ -39,6 +39,7 @@ struct Lds {
     const float2* ray;        // body-frame ray directions
     CarCore* cars;
     LidarFrame* frame;        // [2][cars_per_block], double-buffered by step parity
+    PairCull* pairs;          // [2][cars_per_block][FTGP_PAIR_STRIDE], right behind the frames (multi-car envs only)
     int64_t* steps;
     float* scan;              // [2][cars_per_block][win_floats] scan windows (layout: scan_window_* below), double-buffered by step parity
     int* list;                // [waves_per_block][64] driver scratch
@@ -82,6 +83,7 @@ __device__ __forceinline__ Lds lds_view(const LdsOffsets& o, unsigned char* lds)
     L.ray = reinterpret_cast<const float2*>(lds + opaque(o.ray));
     L.cars = reinterpret_cast<CarCore*>(lds + opaque(o.cars));
     L.frame = reinterpret_cast<LidarFrame*>(lds + opaque(o.frame));
+    L.pairs = reinterpret_cast<PairCull*>(L.frame + 2 * o.cpb);
     L.steps = reinterpret_cast<int64_t*>(lds + opaque(o.steps));
     L.scan = reinterpret_cast<float*>(lds + opaque(o.scan));
     L.list = reinterpret_cast<int*>(lds + opaque(o.list));
@@ -210,7 +212,7 @@ __device__ __forceinline__ void sweep_priority(bool second_half)
 }
 
 template <bool MULTI>
-__device__ __forceinline__ void lidar_pool(const DeviceParams& P, const Lds& L, const LidarFrame* frames, float* scan_rows, int* pool,
+__device__ __forceinline__ void lidar_pool(const DeviceParams& P, const Lds& L, const LidarFrame* frames, const PairCull* pairs, float* scan_rows, int* pool,
                                            int ncars_here, int ci0, bool scan_lds, bool second_half STAMP_ARG)
 {
     typedef const __attribute__((address_space(1))) unsigned char* global_u8;
@@ -243,26 +245,21 @@ __device__ __forceinline__ void lidar_pool(const DeviceParams& P, const Lds& L, 
             const int c = cj >> 16, j = cj & 0xffff;
             float r = hit ? fabsf(ray.s) : ray.result;       // ftgp_ray_range()
             if (MULTI) {
-                // Rays also see the other cars of the env (a9).  Conservative cull before the exact box / puck tests: every
-                // visible part of a car lies within `cull` of its origin, so a car whose origin is farther than that from the
-                // ray, behind its start, or beyond the wall hit cannot change the range.  Results are unaffected.
-                const FtgpVehicle& v = L.veh->v;
-                const LidarFrame* me = frames + c;
-                const float cull = L.veh->cull_radius;
-                const double lcx = me->lcx, lcy = me->lcy;
-                const float ox = (float)lcx - r0 * dxw, oy = (float)lcy - r0 * dyw;
-                const int slot0 = me->slot0;
-                if (!me->finished)
-                    for (int k = 0; k < P.cars_per_env; ++k) {
-                        const LidarFrame* b = frames + slot0 + k;
-                        if (slot0 + k == c || b->finished) continue;          // shadowed cars are invisible (custom.py:1441-1466)
-                        const float wx = b->fx - ox, wy = b->fy - oy;
-                        const float along = wx * dxw + wy * dyw;
-                        const float perp2 = (wx * wx + wy * wy) - along * along;
-                        if (perp2 > cull * cull || along < -cull || (r >= 0.0f && along - cull > r)) continue;
-                        const float rc = ray_vs_car(v, b, lcx, lcy, dxw, dyw);
+                // Rays also see the other cars of the env (a9).  One record per env-mate (PairCull, written with the frames) rules a
+                // mate out with a dot product: it can only be touched if it lies in front of the ray and within `cull` of its line.
+                // The exact box / puck tests run for what is left; results are unaffected by the cull.
+                const PairCull* mates = pairs + c * FTGP_PAIR_STRIDE;
+                for (int k = 0; k < P.cars_per_env; ++k) {
+                    const float4 q = *reinterpret_cast<const float4*>(mates + k);
+                    const float al = fmaf(q.x, dxw, q.y * dyw);
+                    if (al >= q.z) {
+                        const float cull = L.veh->cull_radius;
+                        if (r >= 0.0f && (al + r0) - cull > r) continue;             // the mate lies beyond the wall hit
+                        const LidarFrame* me = frames + c;
+                        const float rc = ray_vs_car(L.veh->v, frames + me->slot0 + k, me->lcx, me->lcy, dxw, dyw);
                         if (rc < INFINITY && (r < 0.0f || rc < r)) r = rc;
                     }
+                }
             }
             // the on-device drivers read ranges[0] and ranges[eighth : n - eighth]: that window is kept in LDS and goes to HBM as whole
             // lines once the sweep is over (window_flush); everything else is stored ray by ray (4-byte stores that merge in L2)
@@ -618,6 +615,20 @@ __device__ __forceinline__ bool frame_write(const DeviceParams& P, const FtgpVeh
     return !finished && u0 >= m && u0 <= (float)P.width - m && v0 >= m && v0 <= (float)P.height - m;      // false for a NaN
 }
 
+// The env-mate records of car c for the frames just written (see PairCull): one lane per (car, mate) pair.
+__device__ __forceinline__ void pair_cull_write(const LidarFrame* frames, PairCull* pairs, int c, int k, int cars_per_env, float cull, float r0)
+{
+    const LidarFrame* me = frames + c;
+    const int mate = me->slot0 + k;
+    PairCull p; p.bx = 0.0f; p.by = 0.0f; p.t = INFINITY; p.pad = 0.0f;
+    if (k < cars_per_env && mate != c && !me->finished && !frames[mate].finished) {
+        p.bx = (float)(frames[mate].x - me->lcx); p.by = (float)(frames[mate].y - me->lcy);
+        const float d2 = p.bx * p.bx + p.by * p.by, close = 2.0f * cull + r0;
+        p.t = d2 <= close * close ? -INFINITY : sqrtf(d2 - cull * cull) * 0.9999f;
+    }
+    pairs[c * FTGP_PAIR_STRIDE + k] = p;
+}
+
 // K1 + K3 for every car of the workgroup by ONE wave, four lanes per car (lane = 4 * car + r).
 //   K1  lane r evaluates wheel r (fl, fr, bl, br), then wall-contact circle r (r < 3), then wheel softener r (bubble_wrap);
 //       the force terms go to an LDS staging row and lane 0 of the car adds them up in the specification's order
@@ -628,7 +639,7 @@ __device__ __forceinline__ bool frame_write(const DeviceParams& P, const FtgpVeh
 //       followed by the head of the next loop iteration.
 // Then the LiDAR frames of the next step are written.
 template <bool MULTI>
-__device__ __forceinline__ void dynamics_lanes(const DeviceParams& P, const Lds& L, LidarFrame* next_frames, int* unsafe_next, int ncars_here, int ci0)
+__device__ __forceinline__ void dynamics_lanes(const DeviceParams& P, const Lds& L, LidarFrame* next_frames, PairCull* next_pairs, int* unsafe_next, int ncars_here, int ci0)
 {
     const int lane = lane_here();
     const int c = lane >> 2, r = lane & 3;
@@ -768,6 +779,14 @@ __device__ __forceinline__ void dynamics_lanes(const DeviceParams& P, const Lds&
     if (on && r == 0) safe = frame_write(P, v, st, next_frames + c, c);
     const bool any_unsafe = __any(!safe);
     if (lane == 0) *unsafe_next = any_unsafe;
+    if (MULTI) {                     // env-mate records of the new frames: lane r of a car writes mates r and r + 4
+        wave_lds_sync();
+        const float cull = L.veh->cull_radius, r0f = (float)v.lidar_ring_radius;
+        if (on) {
+            pair_cull_write(next_frames, next_pairs, c, r, P.cars_per_env, cull, r0f);
+            pair_cull_write(next_frames, next_pairs, c, r + 4, P.cars_per_env, cull, r0f);
+        }
+    }
 }
 
 // Inclusive prefix sum over the 64 lanes of a wave with data-parallel-primitive moves (no LDS round trips): three shifts
@@ -1083,6 +1102,11 @@ __global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(cons
         wave_lds_sync();
         if (lane == 0 && !frame_write(P, L.veh->v, L.cars + c, L.frame + c, c)) atomicOr(L.pool + 4, 1);
     }
+    if (MULTI) {                         // env-mate records of the first frames
+        __syncthreads();
+        const int c = (int)threadIdx.x / FTGP_PAIR_STRIDE, k = (int)threadIdx.x % FTGP_PAIR_STRIDE;
+        if (c < ncars_here) pair_cull_write(L.frame, L.pairs, c, k, P.cars_per_env, L.veh->cull_radius, (float)L.veh->v.lidar_ring_radius);
+    }
     }
     __syncthreads();
 
@@ -1125,7 +1149,7 @@ __global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(cons
             if (n == ncars_here - 1) {            // every driver of the workgroup has delivered its controls
                 if (lane == 0) { L.pool[par ^ 1] = 0; L.pool[2 + (par ^ 1)] = 0; }     // the next step's counters (idle during this step)
 #ifndef FTGP_ABLATE_K1
-                dynamics_lanes<MULTI>(P, L, next_frames, L.pool + 4 + (par ^ 1), ncars_here, ci0);
+                dynamics_lanes<MULTI>(P, L, next_frames, L.pairs + (par ^ 1) * cpb * FTGP_PAIR_STRIDE, L.pool + 4 + (par ^ 1), ncars_here, ci0);
 #endif
                 STAMP(t2); STAMP_ADD(2, t2 - t1); STAMP_ADD(7, 1);
             }
@@ -1135,7 +1159,7 @@ __global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(cons
 #endif
         STAMP(t3);
 #ifndef FTGP_ABLATE_K2
-        lidar_pool<MULTI>(P, L, frames, scan_now, L.pool + par, ncars_here, ci0, need_scan, second_half STAMP_PASS);
+        lidar_pool<MULTI>(P, L, frames, L.pairs + par * cpb * FTGP_PAIR_STRIDE, scan_now, L.pool + par, ncars_here, ci0, need_scan, second_half STAMP_PASS);
 #endif
         STAMP(t4);
         __syncthreads();
