@@ -20,13 +20,19 @@ for name in ("track", "circle", "small-circle", "inkscape"):
         n_big = 4096 if cars == 1 else 1024
         kw = dict(cars_per_env=cars, n_rays=rays, spawn_mode=1 if cars == 1 else 0, seed=99)
         t0 = time.time()
-        with capi.Env(lib, t, n_envs=n_big, **kw) as g, capi.Env(ora, t, n_envs=envs, **kw) as o:
+        # `twin`: the same batch a second time on the GPU, launched in chunks of another size -- every env of the full-size batch is
+        # then checked against an independent run (a race between waves shows as a difference between the two), not only the
+        # oracle's prefix
+        with capi.Env(lib, t, n_envs=n_big, **kw) as g, capi.Env(ora, t, n_envs=envs, **kw) as o, capi.Env(lib, t, n_envs=n_big, **kw) as twin:
             ora.dll.oracle_set_threads(o.h, 16)
             n = envs * cars
             for done in range(0, steps, chunk):
                 g.rollout(policy, chunk); o.rollout(policy, chunk)
+                for part in (chunk // 5, chunk - chunk // 5):
+                    twin.rollout(policy, part)
                 same = (np.array_equal(g.lidar()[:n], o.lidar()) and np.array_equal(g.progress()[:n], o.progress())
-                        and np.array_equal(g.pose()[:n], o.pose()) and np.array_equal(g.ctrl()[:n], o.ctrl()))
+                        and np.array_equal(g.pose()[:n], o.pose()) and np.array_equal(g.ctrl()[:n], o.ctrl())
+                        and np.array_equal(g.lidar(), twin.lidar()) and np.array_equal(g.pose(), twin.pose()) and np.array_equal(g.progress(), twin.progress()))
                 if not same:
                     bad += 1
                     print(f"MISMATCH {name} {policy} x{cars} after {done + chunk} steps", flush=True)
