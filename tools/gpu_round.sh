@@ -1,5 +1,5 @@
 #!/bin/bash
-# One GPU-box visit: parity tests -> bench -> rocprofv3 kernel trace.  A step killed by its timeout ends the visit.
+# One GPU-box visit: parity tests -> smoke -> soak -> the driver's bench shape.  A step killed by its timeout ends the visit.
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"
 mkdir -p gpurun_out
@@ -19,15 +19,16 @@ nproc >> gpurun_out/round.log
 WHAT=${1:-all}
 if [ "$WHAT" = all ] || [ "$WHAT" = test ]; then
     run pytest_gpu 1000 python -m pytest tests -m gpu -x -q ${PYTEST_ARGS:-}
-    tail -25 gpurun_out/pytest_gpu.log
+    tail -5 gpurun_out/pytest_gpu.log
+    run smoke 300 python -c "import __graft_entry__ as g; g.smoke()"
+    tail -2 gpurun_out/smoke.log
+fi
+if [ "$WHAT" = all ] || [ "$WHAT" = soak ]; then
+    run soak 1000 python3 tools/soak.py ${SOAK_STEPS:-4000} 128
+    tail -18 gpurun_out/soak.log
 fi
 if [ "$WHAT" = all ] || [ "$WHAT" = bench ]; then
-    run bench 500 python bench.py --steps ${BENCH_STEPS:-500} --warmup 50
-    tail -3 gpurun_out/bench.log
-fi
-if [ "$WHAT" = all ] || [ "$WHAT" = prof ]; then
-    rm -rf gpurun_out/prof
-    run rocprof 500 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -- python3 bench.py --steps ${BENCH_STEPS:-500} --warmup 50 --no-cpu-baseline
-    find gpurun_out/prof -name "*kernel_stats*.csv" | head -1 | xargs -r head -8
+    run bench20 500 python bench.py --steps 20 --warmup 5
+    tail -1 gpurun_out/bench20.log | cut -c1-400
 fi
 exit 0
