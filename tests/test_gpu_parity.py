@@ -630,3 +630,32 @@ def test_launch_metrics_record_equals_the_metrics_kernel(product, oracle):
         for e in (g, k, o):
             e.step(3)
         np.testing.assert_array_equal(g.metrics_local(), o.metrics_local())
+
+
+def test_config4_all_eight_shards_equal_the_monolithic_batch(product):
+    """BASELINE.json configs[3] at its full size on one GPU: the 32768-env random-policy batch run as ONE handle, and as the eight
+    4096-env shards the 8-GPU job consists of (env_base = rank * 4096, one after the other on this GPU).  Every shard must
+    reproduce its slice of the monolithic batch bit for bit -- spawn poses, random controls, scans, progress -- and the metrics
+    records of the shards must add up to the monolithic one: what the 8-GPU job computes is then what one big GPU would."""
+    from ft_grandprix_amd import dist as ftdist
+    t = load_track("track")
+    kw = dict(n_rays=1080, spawn_mode=1, seed=1234)
+    steps = 40
+    with capi.Env(product, t, n_envs=32768, **kw) as mono:
+        mono.rollout("random", steps)
+        lid, prog, ctrl, pose, rec = mono.lidar(), mono.progress(), mono.ctrl(), mono.pose(), mono.metrics_local()
+    recs = []
+    for rank in range(8):
+        with ftdist.make_shard(product, t, 32768, rank, 8, **kw) as sh:
+            assert (sh.n_envs, sh.env_base) == (4096, rank * 4096)
+            sh.rollout("random", steps)
+            sl = slice(rank * 4096, (rank + 1) * 4096)
+            np.testing.assert_array_equal(sh.lidar(), lid[sl])
+            np.testing.assert_array_equal(sh.progress(), prog[sl])
+            np.testing.assert_array_equal(sh.ctrl(), ctrl[sl])
+            np.testing.assert_array_equal(sh.pose(), pose[sl])
+            recs.append(sh.metrics_local())
+    tot, ref = ftdist.reduce_metrics(np.stack(recs)), ftdist.reduce_metrics(rec[None])
+    for k in capi.METRIC_FIELDS:
+        assert tot[k] == ref[k], k
+    assert tot["steps"] == 32768 * steps and tot["ranks"] == 8
