@@ -323,7 +323,10 @@ __device__ __forceinline__ void lidar_pool(const DeviceParams& P, const Lds& L, 
             // a finished ray idles on its terminal cell: it issues no load (w keeps that cell's entry) and the selects of
             // ftgp_ray_commit() hold it there.  (Running the whole body under the mask of the unfinished lanes instead saves
             // those selects and was measured 4 % slower: the divergent control flow costs more than three instructions.)
-            if (alive) asm volatile("global_load_ushort %0, %1, %2\n\ts_waitcnt vmcnt(0)" : "+v"(w) : "v"(ftgp_ray_offset(ray)), "s"(field));
+#ifndef FTGP_FIELD_LOAD_MOD
+#define FTGP_FIELD_LOAD_MOD ""        // cache-policy bits of the field load (A/B in profiles/round3/ab_field_load.log: none is best)
+#endif
+            if (alive) asm volatile("global_load_ushort %0, %1, %2" FTGP_FIELD_LOAD_MOD "\n\ts_waitcnt vmcnt(0)" : "+v"(w) : "v"(ftgp_ray_offset(ray)), "s"(field));
 #ifdef FTGP_PAD_VALU        // diagnostic (tools/valu_cost.sh): FTGP_PAD_VALU independent filler instructions per march iteration; what one more costs
             {   int pad0 = lane, pad1 = lane + 1; unsigned long long padm; double padd0 = 1.0, padd1 = 2.0;
                 #pragma unroll
