@@ -48,20 +48,20 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
-def committed_counters(name, n_envs, n_rays, cars, policy):
-    """The newest counter summary committed under profiles/roundN by tools/collect_profile.py (rocprofv3 --pmc, separate
-    passes) that was measured on this configuration.  The counters cannot be read from inside this process; `stale` says
-    whether the kernel sources have changed since."""
+def committed_counters(prefix, n_envs, n_rays, cars, policy, track="track"):
+    """The newest counter summary (`<prefix>_*.json`) committed under profiles/roundN by tools/collect_profile.py (rocprofv3 --pmc,
+    separate passes) that was measured on this configuration.  The counters cannot be read from inside this process; `stale`
+    says whether the kernel sources have changed since."""
+    import glob
     for d in PROFILE_DIRS:
-        p = os.path.join(d, name)
-        if not os.path.exists(p):
-            continue
-        t = json.load(open(p))
-        if (t.get("n_envs"), t.get("n_rays", 1080), t.get("cars", 1), t.get("policy", "fast")) != (n_envs, n_rays, cars, policy):
-            continue
-        t["stale"] = t.get("kernel_source_sha") != kernel_source_sha()
-        t["file"] = os.path.relpath(p, ROOT)
-        return t
+        for p in sorted(glob.glob(os.path.join(d, prefix + "_*.json"))):
+            t = json.load(open(p))
+            have = (t.get("n_envs"), t.get("n_rays", 1080), t.get("cars", 1), t.get("policy", "fast"), t.get("track", "track"))
+            if have != (n_envs, n_rays, cars, policy, track):
+                continue
+            t["stale"] = t.get("kernel_source_sha") != kernel_source_sha()
+            t["file"] = os.path.relpath(p, ROOT)
+            return t
     return None
 
 
@@ -269,7 +269,7 @@ def main():
                 # limits the kernel is vector-instruction issue, far above the HBM ridge -- see `valu`
                 "limiter": "vector-instruction issue: the SIMDs' vector pipes are busy ~100 % of the time (valu.busy_frac) with "
                            "instructions that cost 2-4 cycles each; HBM traffic is a few percent of peak"}
-        tr = committed_counters("traffic_latest.json", args.envs_per_gpu, args.rays, args.cars, args.policy)
+        tr = committed_counters("traffic", args.envs_per_gpu, args.rays, args.cars, args.policy, args.track)
         if tr is not None:
             # HBM bytes per launch = the committed PMC figure per env-step (FETCH_SIZE x2 + WRITE_SIZE, separate passes) scaled to this launch
             roof["traffic"] = tr["traffic_bytes_per_env_step"] * args.envs_per_gpu * args.steps
@@ -278,7 +278,7 @@ def main():
             roof["traffic_source"] = {"file": tr["file"], "measured_in_this_run": False,
                                       "kernel_source_sha": tr.get("kernel_source_sha"), "stale": tr["stale"],
                                       "bytes_per_env_step": tr["traffic_bytes_per_env_step"]}
-        sq = committed_counters("sq_latest.json", args.envs_per_gpu, args.rays, args.cars, args.policy)
+        sq = committed_counters("sq", args.envs_per_gpu, args.rays, args.cars, args.policy, args.track)
         if sq is not None:
             c, steps_c = sq["counters"], sq["steps"]
             valu_per_car_step = c["SQ_INSTS_VALU"] / (sq["n_envs"] * sq.get("cars", 1) * steps_c)
