@@ -659,3 +659,31 @@ def test_config4_all_eight_shards_equal_the_monolithic_batch(product):
     for k in capi.METRIC_FIELDS:
         assert tot[k] == ref[k], k
     assert tot["steps"] == 32768 * steps and tot["ranks"] == 8
+
+
+@pytest.mark.parametrize("case", range(8))
+def test_randomised_worlds(product, oracle, case):
+    """Seeded differential test over the whole configuration space at once: procedural tracks of odd sizes (square and stretched
+    pixels, thin and thick corridors), ray counts, cars per env, batch sizes that leave workgroups ragged, drivers, friction,
+    bubble_wrap -- every combination closed-loop against the oracle, state compared after uneven launches."""
+    from ft_grandprix_amd.track import synthetic_oval
+    rng = np.random.default_rng(1000 + case)
+    w = int(rng.integers(300, 900)); h = int(rng.integers(260, 700))
+    t = synthetic_oval(width=w, height=h, half_width_px=float(rng.uniform(14, 30)), wall_px=float(rng.uniform(0.8, 2.5)),
+                       name=f"rand{case}", frame=("mjcf", "pixel")[case % 2] if case % 3 else "mjcf")
+    cars = int(rng.choice([1, 1, 2, 3, 5]))
+    rays = int(rng.choice([8, 24, 90, 333, 720, 1080, 1500]))
+    envs = int(rng.integers(3, 70))
+    policy = str(rng.choice(["nidc", "fast", "nidc", "fast", "random", "lobotomy"]))
+    v = product.default_vehicle()
+    v.friction = float(rng.uniform(0.3, 1.5))
+    kw = dict(n_envs=envs, cars_per_env=cars, n_rays=rays, spawn_mode=int(rng.integers(0, 2)), seed=int(rng.integers(1, 10 ** 6)),
+              lap_target=0 if case == 0 else int(rng.integers(1, 4)), bubble_wrap=bool(rng.integers(0, 2)), vehicle=v)
+    g, o = capi.Env(product, t, **kw), capi.Env(oracle, t, **kw)
+    oracle.dll.oracle_set_threads(o.h, 8)
+    with g, o:
+        for n in (1, int(rng.integers(2, 40)), int(rng.integers(40, 260))):
+            g.rollout(policy, n); o.rollout(policy, n)
+            assert_same_state(g, o)
+        np.testing.assert_array_equal(g.winners(), o.winners())
+        np.testing.assert_array_equal(g.metrics_local(), o.metrics_local())
