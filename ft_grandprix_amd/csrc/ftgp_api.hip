@@ -351,7 +351,7 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
     if (t.width > 8192 || t.height > 8192) return fail(FTGP_ERR_ARG, "images above 8192 pixels are not supported%s");
     // the march addresses the box field with a 32-bit byte offset (ftgp_ray_offset: plane << 8 + cell offsets)
     if ((uint64_t)ftgp_plane256(t.width, t.height) * 256u * FTGP_SECTORS > 0xFFFFFFFFull)
-        return fail(FTGP_ERR_ARG, "track image too large: the sector box field (64 bytes per pixel) must stay below 4 GiB (about 67 million pixels)%s");
+        return fail(FTGP_ERR_ARG, "track image too large: the sector box field (128 bytes per pixel) must stay below 4 GiB (about 33 million pixels)%s");
     if (cfg->env_base < 0) return fail(FTGP_ERR_ARG, "env_base < 0%s");
     if (!(cfg->dt > 0.0) || !(t.px_size_x > 0.0) || !(t.px_size_y > 0.0)) return fail(FTGP_ERR_ARG, "bad dt / pixel size%s");
     const FtgpVehicle& v = cfg->vehicle;

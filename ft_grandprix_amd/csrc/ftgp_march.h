@@ -9,7 +9,7 @@
 //
 // Sector box field.  Both axes are mirrored so that every ray travels towards +x', +y' (x' = -x is exact in IEEE
 // arithmetic and maps cell i to ~i).  Directions are binned into FTGP_SECTORS = 8 * NS sectors: the octant (mirror x, mirror y,
-// dominant axis) and, inside it, NS equal slices of the slope minor/major (NS = 1, 2 or 4).  For each pixel and sector one 16-bit
+// dominant axis) and, inside it, NS equal slices of the slope minor/major (NS = 1, 2, 4 or 8; 8 is shipped).  For each pixel and sector one 16-bit
 // entry holds a box of pixels with its corner at the pixel, extending AHEAD of the ray: low byte kx, high byte ky (cells
 // along x' / y'); 0 = the pixel is a wall.  Only the part of the box that a ray of the sector can reach from anywhere
 // inside the pixel has to be wall-free (the cone of the sector, widened by one cell so that rays through pixel corners --
@@ -38,11 +38,11 @@ FTGP_HD float ftgp_float(uint32_t b) { float x; memcpy(&x, &b, 4); return x; }
 
 #define FTGP_FIELD_OUT 0x0100u
 #ifndef FTGP_SECTORS
-#define FTGP_SECTORS 32
+#define FTGP_SECTORS 64
 #endif
 
 #define FTGP_SLOPE_SLICES (FTGP_SECTORS / 8)
-static_assert(FTGP_SECTORS == 8 || FTGP_SECTORS == 16 || FTGP_SECTORS == 32, "8, 16 or 32 sectors");
+static_assert(FTGP_SECTORS == 8 || FTGP_SECTORS == 16 || FTGP_SECTORS == 32 || FTGP_SECTORS == 64, "8, 16, 32 or 64 sectors");
 
 // Entry of pixel (x, y) for sector = (mirror x) | (mirror y) << 1 | (y-dominant) << 2 | (slope slice) << 3.
 //   runx[d][y][x] wall-free run length starting at the pixel along +x (d = 0) / -x (d = 1); runy likewise
@@ -155,12 +155,20 @@ FTGP_HD void ftgp_ray_init(FtgpRay& r, float pu, float pv, float du, float dv, f
     r.s = 0.0f;
     if (!assume_inside) r.result = -1.0f;
     uint32_t sector = ((uint32_t)mxm & 1u) | ((uint32_t)mym & 2u) | (ydom ? 4u : 0u);
-    {   // slope slice: the number of k in 1 .. NS - 1 with NS * minor > k * major; "a > b" as the sign of the rounded b - a
-        // (a rounded difference has the sign of the exact one, and equal operands give +0)
-        const float mn = ydom ? adu : adv, mj = ydom ? adv : adu;
-        if (FTGP_SLOPE_SLICES == 2) sector |= (ftgp_bits(fmaf(-2.0f, mn, mj)) >> 31) << 3;
-        if (FTGP_SLOPE_SLICES == 4)
-            sector |= ((ftgp_bits(fmaf(-4.0f, mn, mj)) >> 31) + (ftgp_bits(fmaf(-2.0f, mn, mj)) >> 31) + (ftgp_bits(fmaf(-4.0f, mn, 3.0f * mj)) >> 31)) << 3;
+    if (FTGP_SLOPE_SLICES > 1) {
+        // slope slice = floor(NS * minor / major), with the reciprocal of the major component that is at hand anyway.  A few units
+        // of rounding may put a ray that runs along a slice boundary into the neighbouring slice: harmless, the boxes of a
+        // slice hold for every slope within a cell's margin of it (ftgp_box_entry), and a box that holds gives the
+        // specification's result whichever slice it came from.  The factor just below NS keeps slope 1 in the last slice.
+        const float mn = ydom ? adu : adv, inv_mj = ydom ? ivy : ivx;
+        const float scaled = (mn * inv_mj) * ((float)FTGP_SLOPE_SLICES * 0.99999f);
+#if defined(__HIP_DEVICE_COMPILE__)
+        int slice; asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(slice) : "v"(scaled));
+#else
+        int slice = (int)floorf(scaled);
+#endif
+        // (a direction of (0, 0) or a NaN cannot occur: the components are a rotated unit vector, scaled)
+        sector |= (uint32_t)slice << 3;
     }
     r.ix = ix0 ^ mxm; r.iy = iy0 ^ mym;
     const int hy = (fstride ^ mym) - mym;                     // +-fstride

@@ -53,7 +53,7 @@ def test_bad_arguments_are_rejected(oracle):
 
 
 def test_box_field_must_stay_addressable_with_32_bits(product):
-    """The march addresses the sector box field (32 planes x 2 bytes per pixel, ring included) with a 32-bit byte offset:
+    """The march addresses the sector box field (64 planes x 2 bytes per pixel, ring included) with a 32-bit byte offset:
     ftgp_create refuses an image whose field would reach 4 GiB instead of wrapping silently.  Error path only -- the check
     sits in front of the device probe and allocates nothing (the bitmap pointer is never read)."""
     class Huge:
@@ -65,7 +65,7 @@ def test_box_field_must_stay_addressable_with_32_bits(product):
     with pytest.raises(capi.FtgpError) as ei:
         capi.Env(product, Huge, n_envs=1, n_rays=8)
     assert ei.value.code == -1 and "4 GiB" in str(ei.value)
-    assert (2 * 8194 * 8194 + 255) // 256 * 256 * 32 > 2 ** 32 > (2 * 8194 * 8183 + 255) // 256 * 256 * 32     # 8192 x 8181 is the last height that fits
+    assert (2 * 8194 * 4096 + 255) // 256 * 256 * 64 > 2 ** 32 >= (2 * 8194 * 4095 + 255) // 256 * 256 * 64    # 8192 x 4093 is the last height that fits
 
 
 def test_product_package_never_references_the_oracle():
