@@ -390,6 +390,7 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
     P.bubble_wrap = cfg->bubble_wrap ? 1 : 0;        // cfg->naive_flatten: accepted, no effect on a planar model (custom.py:1338-1339)
     P.width = t.width; P.height = t.height; P.words_per_row = t.words_per_row; P.fstride = t.width + 2;
     P.plane256 = ftgp_plane256(t.width, t.height);
+    for (uint32_t q = 0; q < FTGP_SECTORS; ++q) ftgp_sector_entry(P.sector_tab[q], q, t.width + 2, P.plane256);
     P.px_size_x = t.px_size_x; P.px_size_y = t.px_size_y; P.origin_x = t.origin_x; P.origin_y = t.origin_y;
     P.inv_px_x = 1.0 / t.px_size_x; P.inv_px_y = 1.0 / t.px_size_y;
     P.inv_px_x_f = (float)P.inv_px_x; P.inv_px_y_f = (float)P.inv_px_y;

@@ -89,6 +89,7 @@ struct DeviceParams {
     unsigned int* wg_ticket;
     double* metrics_dev;
     double* metrics_host;
+    alignas(16) int32_t sector_tab[FTGP_SECTORS][4];     // ftgp_sector_entry() of every sector (staged into LDS with the head of the block)
     FtgpVehicle veh;              // host-side copy (the step kernel reads the LDS image VehLds; from here on nothing is staged into LDS)
     double wheel_load[4];
 };

@@ -303,7 +303,8 @@ __device__ __forceinline__ void lidar_pool(const DeviceParams& P, const Lds& L, 
                 const float pv = fmaf(dv, -r0, f4.y);
                 float ivx, ivy;
                 rcp_abs2(du, dv, ivx, ivy);
-                ftgp_ray_init(ray, pu, pv, du, dv, ivx, ivy, W, H, fstride, plane256, true);      // result stays -1 (ftgp_ray_park above)
+                // result stays -1 (ftgp_ray_park above); offsets and strides of the ray's sector come out of the LDS table
+                ftgp_ray_init(ray, pu, pv, du, dv, ivx, ivy, W, H, fstride, plane256, true, &P.sector_tab[0][0]);
                 if (!all_safe) {         // wave-uniform, rare: some car of the workgroup is near the image edge, off it, or has finished
                     ftgp_ray_park_if_outside(ray, pu, pv, W, H);
                     // a finished car's rangefinders are switched off (custom.py:1436-1439): its frame carries u0 = -inf, so the ray is

@@ -127,8 +127,18 @@ FTGP_HD void ftgp_ray_park(FtgpRay& r, float result)
 // assume_inside (a compile-time constant at every call site): the caller guarantees that (pu, pv) is finite and lies on the
 // image -- the step kernel does when every LiDAR centre of the workgroup is a ring radius plus two pixels away from the image
 // edge (frame_write) -- so the test, and the selects that park an off-image ray, are not needed.
+// sector_tab (optional, [FTGP_SECTORS][4] as ftgp_sector_entry() fills it): offC, ax, ay of every sector precomputed, one 16-byte
+// read instead of eight integer instructions.
+FTGP_HD void ftgp_sector_entry(int32_t* e, uint32_t sector, int fstride, uint32_t plane256)
+{
+    const int mxm = -(int)(sector & 1u), mym = -(int)((sector >> 1) & 1u);
+    const int hy = (fstride ^ mym) - mym;
+    e[0] = (int)((sector * plane256) << 8) + (fstride + 2) + (mxm + mxm) + hy;
+    e[1] = 2 + 4 * mxm; e[2] = hy + hy; e[3] = 0;
+}
+
 FTGP_HD void ftgp_ray_init(FtgpRay& r, float pu, float pv, float du, float dv, float ivx, float ivy, int W, int H, int fstride, uint32_t plane256,
-                           bool assume_inside = false)
+                           bool assume_inside = false, const int32_t* sector_tab = nullptr)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     int ix0, iy0;                                             // floor and convert in one instruction; the conversion saturates
@@ -171,6 +181,17 @@ FTGP_HD void ftgp_ray_init(FtgpRay& r, float pu, float pv, float du, float dv, f
         sector |= (uint32_t)slice << 3;
     }
     r.ix = ix0 ^ mxm; r.iy = iy0 ^ mym;
+    if (sector_tab) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int4 e4 = reinterpret_cast<const int4*>(sector_tab)[sector];       // one 16-byte LDS read
+        r.offC = e4.x; r.ax = e4.y; r.ay = e4.z;
+#else
+        const int32_t* e = sector_tab + 4 * sector;
+        r.offC = e[0]; r.ax = e[1]; r.ay = e[2];
+#endif
+        if (!inside) { r.offC = 0; r.ax = r.ay = 0; }
+        return;
+    }
     const int hy = (fstride ^ mym) - mym;                     // +-fstride
     r.ax = 2 + 4 * mxm; r.ay = hy + hy;                       // +-2, +-2 * fstride
     // 2 * (x + 1) = ix * ax + (ax + 2) / 2 - ... : both complements cost half their stride, hence (ax + ay) / 2 = 1 + 2 * mxm + hy
