@@ -232,6 +232,7 @@ __device__ __forceinline__ void lidar_pool(const DeviceParams& P, const Lds& L, 
 
     FtgpRay ray; ftgp_ray_park(ray, -1.0f);
     float dxw = 0.0f, dyw = 0.0f;
+    float s_in = 0.0f;               // crossing time into the cell of the lane's latest lookup
     int cj = -1;                     // (car slot << 16 | ray) of the ray this lane is marching (or has just finished); -1: none
     bool done = true;                // the lane's ray sits on its terminal cell (or the lane has none)
     bool pool_empty = false;         // wave-uniform
@@ -243,7 +244,7 @@ __device__ __forceinline__ void lidar_pool(const DeviceParams& P, const Lds& L, 
         // ---- finished rays: store the range ...
         if (done && cj >= 0) {
             const int c = cj >> 16, j = cj & 0xffff;
-            float r = hit ? fabsf(ray.s) : ray.result;       // ftgp_ray_range()
+            float r = hit ? fabsf(s_in) : ray.result;        // ftgp_ray_range()
             if (MULTI) {
                 // Rays also see the other cars of the env (a9).  One record per env-mate (PairCull, written with the frames) rules a
                 // mate out with a dot product: it can only be touched if it lies in front of the ray and within `cull` of its line.
@@ -321,13 +322,20 @@ __device__ __forceinline__ void lidar_pool(const DeviceParams& P, const Lds& L, 
         uint32_t w = FTGP_FIELD_OUT;
         bool alive = cj >= 0;            // lanes whose ray is known to sit on its terminal cell keep that cell's entry and issue no load
         for (int guard = 0; guard < 4 * 8192; ++guard) {
-            // a finished ray idles on its terminal cell: it issues no load (w keeps that cell's entry) and the selects of
-            // ftgp_ray_commit() hold it there.  (Running the whole body under the mask of the unfinished lanes instead saves
-            // those selects and was measured 4 % slower: the divergent control flow costs more than three instructions.)
+            // a finished ray idles: it issues no load (w keeps its terminal cell's entry, so st.live stays false).  The crossing
+            // time into the cell that is looked up is put aside under the load's mask (s_in: a move where there is a mask anyway)
+            // -- for the lookup that ends the ray that is its range -- and the ray's cell and time, never used again, are left
+            // to drift: no select holds them.  (Running the whole body under the mask of the unfinished lanes instead was
+            // measured 4 % slower: the divergent control flow costs more than the selects it saves.)
 #ifndef FTGP_FIELD_LOAD_MOD
 #define FTGP_FIELD_LOAD_MOD ""        // cache-policy bits of the field load (A/B in profiles/round3/ab_field_load.log: none is best)
 #endif
-            if (alive) asm volatile("global_load_ushort %0, %1, %2" FTGP_FIELD_LOAD_MOD "\n\ts_waitcnt vmcnt(0)" : "+v"(w) : "v"(ftgp_ray_offset(ray)), "s"(field));
+            // (one statement: entry offset = ftgp_ray_offset(), the move, the load -- the compiler pads between separate ones)
+            int off;
+            if (alive) asm volatile("v_mad_i32_i24 %2, %3, %4, %5\n\tv_mad_i32_i24 %2, %6, %7, %2\n\tv_mov_b32 %0, %8\n\t"
+                                    "global_load_ushort %1, %2, %9" FTGP_FIELD_LOAD_MOD "\n\ts_waitcnt vmcnt(0)"
+                                    : "+v"(s_in), "+v"(w), "=&v"(off)
+                                    : "v"(ray.iy), "v"(ray.ay), "v"(ray.offC), "v"(ray.ix), "v"(ray.ax), "v"(ray.s), "s"(field));
 #ifdef FTGP_PAD_VALU        // diagnostic (tools/valu_cost.sh): FTGP_PAD_VALU independent filler instructions per march iteration; what one more costs
             {   int pad0 = lane, pad1 = lane + 1; unsigned long long padm; double padd0 = 1.0, padd1 = 2.0;
                 #pragma unroll
@@ -342,7 +350,7 @@ __device__ __forceinline__ void lidar_pool(const DeviceParams& P, const Lds& L, 
             live_mask = __builtin_amdgcn_ballot_w64(st.live);           // here, next to the comparison: the mask is its result
             int t = st.t;
             if (__any(near)) { const int tf = ftgp_ray_fix(ray, st); t = near ? tf : t; }
-            ftgp_ray_commit(ray, st, t);
+            ftgp_ray_commit(ray, st, t, false);
             alive = st.live;
             STAMP_ADD(11, 1);
             if (FTGP_WAVE - __popcll(live_mask) >= want) break;

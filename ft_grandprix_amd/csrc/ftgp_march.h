@@ -290,12 +290,15 @@ FTGP_HD int ftgp_ray_fix(const FtgpRay& r, const FtgpStep& st)
     return t + (inc ? 1 : 0) - (dec ? 1 : 0);
 }
 
-// Second half.  A finished ray stays on its terminal cell and keeps the crossing time into it.
-FTGP_HD void ftgp_ray_commit(FtgpRay& r, const FtgpStep& st, int t)
+// Second half.  With hold (the default) a finished ray stays on its terminal cell and keeps the crossing time into it.
+// hold = false (a compile-time constant at the call site) is for a caller that never looks a finished ray's cell up again and
+// has put the crossing time aside before the lookup that ended the ray (the step kernel: a finished lane issues no load and
+// keeps the terminal entry): cell and time of a finished ray then drift, which saves the three selects that would hold them.
+FTGP_HD void ftgp_ray_commit(FtgpRay& r, const FtgpStep& st, int t, bool hold = true)
 {
     const int nix = st.stepx ? st.xe : t, niy = st.stepx ? t : st.ye;
-    r.ix = st.live ? nix : r.ix; r.iy = st.live ? niy : r.iy;
-    r.s = st.live ? st.sn : r.s;
+    if (hold) { r.ix = st.live ? nix : r.ix; r.iy = st.live ? niy : r.iy; r.s = st.live ? st.sn : r.s; }
+    else { r.ix = nix; r.iy = niy; r.s = st.sn; }
 }
 
 // Range of a ray that sits on its terminal cell, whose entry is w: the crossing time into a wall cell, `result` (-1, or 0 for a
