@@ -850,47 +850,49 @@ __device__ __forceinline__ void policy_disparity(const DeviceParams& P, float* _
     float* __restrict__ proc = scan + scan_window_first(eighth);
     const float range0 = scan[P.win_floats - 1];                    // ranges[0], fast.py:135
     const int kmax = P.cover_kmax;                                  // thr = the cover-count thresholds of this driver (width = (car_width / 2) * (1 + 300 / 100), nidc.py:93)
-    // disparity flags (nidc.py:26-40, on the unmodified scan): lane l owns the contiguous samples [l * chunk, (l + 1) * chunk) and
-    // keeps its flags as bits of mymask; launch_steps() guarantees m <= 64 * 64, i.e. chunk <= 64
-    const int chunk = (m + FTGP_WAVE - 1) / FTGP_WAVE;
-    const int first = lane * chunk, end = min(m, first + chunk);
+    // Disparity flags (nidc.py:26-40, on the unmodified scan): lane l looks at samples l, 64 + l, 128 + l, ... (launch_steps()
+    // guarantees m <= 64 * 64, i.e. K <= 64), so index order is (k, lane) order and a disparity's place in the ordered list is
+    // the running total plus its rank among the flagged lanes of its k.  Disparities are rare: the common path of a k is two
+    // LDS reads, a subtraction and ONE comparison (is anything at or above the threshold?); flags, ranks and list entries
+    // are worked out only where that says yes.  Lanes past the end of the window (and sample 0, which has no predecessor)
+    // read whatever lies there and are masked where it matters.
     // The reference compares |cur - prev| in binary64 with 0.6 (nidc.py:33).  In binary32, with T the float next above 0.6
     // (the nearest one): rounding is monotone, so |fl(cur - prev)| > T implies the exact difference is > 0.6 and < T implies it
     // is not; only a difference that rounds to exactly T needs the binary64 comparison (NaNs fail every test, as there).
-    uint64_t mymask = 0;
+    const int K = (m + FTGP_WAVE - 1) / FTGP_WAVE;
+    uint64_t mymask = 0;             // bit k: sample 64 k + lane is a disparity (needed again only beyond 64 disparities)
+    int total = 0;                   // wave-uniform
     {
         const float T = 0.60000002384185791015625f;
-        uint64_t unsure = 0;
-        float prev = (first >= 1 && first < m) ? proc[first - 1] : 0.0f;
-        for (int i = first; i < end; ++i) {
-            const float cur = proc[i];
+        for (int k = 0; k < K; ++k) {
+            const int i = k * FTGP_WAVE + lane;
+            const float cur = proc[i], prev = proc[i - 1];
             const float ad = fabsf(cur - prev);
-            mymask |= (uint64_t)((i >= 1) && ad > T) << (i - first);
-            unsure |= (uint64_t)((i >= 1) && ad == T) << (i - first);
-            prev = cur;
-        }
-        if (__any(unsure != 0)) {
-            uint64_t mk = unsure;
-            while (mk) {
-                const int bit = __builtin_ctzll(mk);
-                mk &= mk - 1;
-                const int i = first + bit;
-                if (fabs((double)proc[i] - (double)proc[i - 1]) > 0.6) mymask |= 1ull << bit;
+            if (__any(ad >= T)) {
+                const bool valid = i >= 1 && i < m;
+                bool fl = valid && ad > T;
+                if (valid && ad == T) fl = fabs((double)cur - (double)prev) > 0.6;
+                const uint64_t f = __builtin_amdgcn_ballot_w64(fl);
+                if (fl) {
+                    const int r = total + rank_below(f);
+                    if (r < FTGP_WAVE) list[r] = i;
+                    mymask |= 1ull << k;
+                }
+                total += __popcll(f);
             }
         }
     }
-    const int cnt = __popcll(mymask);
-    const int incl = wave_inclusive_sum(cnt);
-    const int excl = incl - cnt;
-    const int total = __builtin_amdgcn_readlane(incl, FTGP_WAVE - 1);
     for (int c0 = 0; c0 < total; c0 += FTGP_WAVE) {
-        {   // indices of disparities c0 .. c0 + 63, in order: lane l owns the set bits of its samples
-            uint64_t mk = mymask; int rank = excl;
-            while (mk) {
-                const int bit = __builtin_ctzll(mk);
-                mk &= mk - 1;
-                if (rank >= c0 && rank < c0 + FTGP_WAVE) list[rank - c0] = first + bit;
-                ++rank;
+        if (c0 > 0) {                // disparities c0 .. c0 + 63 of more than 64: their indices again, from the kept flags
+            int run = 0;
+            for (int k = 0; k < K; ++k) {
+                const bool fl = ((mymask >> k) & 1ull) != 0;
+                const uint64_t f = __builtin_amdgcn_ballot_w64(fl);
+                if (fl) {
+                    const int r = run + rank_below(f) - c0;
+                    if (r >= 0 && r < FTGP_WAVE) list[r] = k * FTGP_WAVE + lane;
+                }
+                run += __popcll(f);
             }
         }
         wave_lds_sync();
@@ -922,11 +924,20 @@ __device__ __forceinline__ void policy_disparity(const DeviceParams& P, float* _
         }
     }
     wave_lds_sync();
-    // argmax, first maximum (nidc.py:127): every lane scans its own samples in index order, lanes are merged with "the lower
-    // index wins ties"; sample 0 is the running maximum to begin with, whatever it is (a NaN there stays, like numpy's loop)
+    // argmax, first maximum (nidc.py:127): every lane scans its own samples (l, 64 + l, ...) in index order, lanes are merged with
+    // "the lower index wins ties"; sample 0 is the running maximum to begin with, whatever it is (a NaN there stays, like numpy's loop)
     float bv = -INFINITY; int bi = 0x7fffffff;
     if (lane == 0) { bv = proc[0]; bi = 0; }
-    for (int i = first + (lane == 0 ? 1 : 0); i < end; ++i) { const float x = proc[i]; if (x > bv) { bv = x; bi = i; } }
+    for (int k = 0; k < K - 1; ++k) {                               // all of these are inside the window
+        const int i = k * FTGP_WAVE + lane;
+        const float x = proc[i];
+        if (x > bv) { bv = x; bi = i; }
+    }
+    {
+        const int i = (K - 1) * FTGP_WAVE + lane;
+        const float x = proc[i];
+        if (i < m && x > bv) { bv = x; bi = i; }
+    }
     #pragma unroll
     for (int mm = 32; mm >= 1; mm >>= 1) {
         const float ov = __shfl_xor(bv, mm, FTGP_WAVE);

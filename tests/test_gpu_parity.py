@@ -199,6 +199,31 @@ def test_disparity_threshold_edge_cases(product, oracle):
         assert len(np.unique(g.policy_eval("nidc", scans)[:, 1])) > 4
 
 
+def test_k5_wide_window_and_many_disparities(product, oracle):
+    """K5 walks the front window 64 samples at a time and lists disparities 64 at a time: windows of more than 32 x 64 samples
+    (64-bit flag words), scans with thousands of disparities (many list chunks, rebuilt from the kept flags), and windows
+    that end in the middle of a 64-sample group -- against the oracle, exactly."""
+    rng = np.random.default_rng(11)
+    t = load_track("small-circle")
+    for R in (4000, 1081, 200):
+        scans = np.empty((12, R), dtype=np.float32)
+        for row in range(12):
+            base = rng.uniform(0.5, 6.0, R).astype(np.float32) if row % 3 == 0 else np.full(R, 3.0, dtype=np.float32)
+            if row % 3 == 1:                                    # a few hundred steps of random height
+                for at in rng.choice(R, size=min(R // 4, 300), replace=False):
+                    base[at:] += np.float32(rng.choice([-0.7, 0.7, 1.3]))
+                base = np.abs(base) + np.float32(0.2)
+            if row % 3 == 2:                                    # smooth, one disparity at each end of the window
+                e = R // 8
+                base[e + 1:] += np.float32(1.0); base[R - e - 1:] += np.float32(1.0)
+            if row % 4 == 3:
+                base[rng.integers(0, R, 5)] = np.float32(-1.0)      # rays that hit nothing
+            scans[row] = base
+        with capi.Env(product, t, n_envs=len(scans), n_rays=R) as g, capi.Env(oracle, t, n_envs=len(scans), n_rays=R) as o:
+            for name in ("nidc", "fast"):
+                np.testing.assert_array_equal(g.policy_eval(name, scans), o.policy_eval(name, scans), err_msg=f"{name} R={R}")
+
+
 @pytest.mark.parametrize("trace", ["forward", "reverse_start", "back_and_forth", "fast_jumps"])
 def test_g5_progress_block_on_gpu(product, trace):
     """K3 against the reference's progress block executed verbatim (fixture g5_progress.npz)."""
