@@ -387,6 +387,7 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
     P.n_rays = cfg->n_rays; P.lap_target = cfg->lap_target; P.spawn_mode = cfg->spawn_mode; P.env_base = cfg->env_base;
     P.ranges_stride = (cfg->n_rays + 31) & ~31;      // rows start on 128-B boundaries
     P.seed = cfg->seed; P.dt = cfg->dt;
+    P.rpp = (2 * M_PI) / (double)cfg->n_rays;
     P.bubble_wrap = cfg->bubble_wrap ? 1 : 0;        // cfg->naive_flatten: accepted, no effect on a planar model (custom.py:1338-1339)
     P.width = t.width; P.height = t.height; P.words_per_row = t.words_per_row; P.fstride = t.width + 2;
     P.plane256 = ftgp_plane256(t.width, t.height);

@@ -56,6 +56,7 @@ struct DeviceParams {
     int32_t lap_target, spawn_mode, ranges_stride, env_base;
     uint64_t seed;
     double dt;
+    double rpp;                   // radians per LiDAR point, (2 pi) / n_rays (nidc.py:121), divided once on the host
     // track
     int32_t width, height, words_per_row, fstride;      // fstride = width + 2: cells per row of a field plane (one-pixel ring)
     double px_size_x, px_size_y, origin_x, origin_y, inv_px_x, inv_px_y;

@@ -817,6 +817,29 @@ __device__ __forceinline__ int wave_inclusive_sum(int x)
     return v;
 }
 
+// Maximum / minimum over the 64 lanes of a wave, same moves, fused into the arithmetic: shifts by 1, 2, 4, 8 inside each row of
+// 16 lanes leave a row's result in its lane 15, the two broadcasts carry it on; lane 63 holds the wave's.  A lane that a step
+// does not address keeps its value.  (One asm statement each: the compiler emits move + DPP move + max per step; the waits
+// are the two states a DPP read needs after the write of its source.)
+#define FTGP_DPP_REDUCE(op) \
+    "s_nop 1\n\t" op " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+    "s_nop 1\n\t" op " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t" \
+    "s_nop 1\n\t" op " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t" \
+    "s_nop 1\n\t" op " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t" \
+    "s_nop 1\n\t" op " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t" \
+    "s_nop 1\n\t" op " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t" \
+    "s_nop 1"
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t x)
+{
+    asm volatile(FTGP_DPP_REDUCE("v_max_u32_dpp") : "+v"(x));
+    return (uint32_t)__builtin_amdgcn_readlane((int)x, FTGP_WAVE - 1);
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t x)
+{
+    asm volatile(FTGP_DPP_REDUCE("v_min_u32_dpp") : "+v"(x));
+    return (uint32_t)__builtin_amdgcn_readlane((int)x, FTGP_WAVE - 1);
+}
+
 // =============================================================================================
 // K5: on-device drivers.  nidc.py:12-131 / fast.py:11-139 restated for one wave; the previous scan sits in LDS.
 // =============================================================================================
@@ -844,7 +867,7 @@ __device__ __forceinline__ void policy_disparity(const DeviceParams& P, float* _
 {
     const int lane = lane_here();
     const int n = P.n_rays;
-    const double rpp = (2 * M_PI) / (double)n;                      // nidc.py:121
+    const double rpp = P.rpp;                                       // (2 pi) / n, nidc.py:121
     const int eighth = P.eighth;                                    // int(n / 8), nidc.py:18
     const int m = n - 2 * eighth;
     float* __restrict__ proc = scan + scan_window_first(eighth);
@@ -864,21 +887,28 @@ __device__ __forceinline__ void policy_disparity(const DeviceParams& P, float* _
     int total = 0;                   // wave-uniform
     {
         const float T = 0.60000002384185791015625f;
-        for (int k = 0; k < K; ++k) {
+        const float* __restrict__ p = proc + lane;                  // sample 64 k + lane is p[64 k]
+        auto flagged = [&](int k, float cur, float prev, float ad) {    // some lane of group k is at or above the threshold
             const int i = k * FTGP_WAVE + lane;
-            const float cur = proc[i], prev = proc[i - 1];
-            const float ad = fabsf(cur - prev);
-            if (__any(ad >= T)) {
-                const bool valid = i >= 1 && i < m;
-                bool fl = valid && ad > T;
-                if (valid && ad == T) fl = fabs((double)cur - (double)prev) > 0.6;
-                const uint64_t f = __builtin_amdgcn_ballot_w64(fl);
-                if (fl) {
-                    const int r = total + rank_below(f);
-                    if (r < FTGP_WAVE) list[r] = i;
-                    mymask |= 1ull << k;
-                }
-                total += __popcll(f);
+            const bool valid = i >= 1 && i < m;
+            bool fl = valid && ad > T;
+            if (valid && ad == T) fl = fabs((double)cur - (double)prev) > 0.6;
+            const uint64_t f = __builtin_amdgcn_ballot_w64(fl);
+            if (fl) {
+                const int r = total + rank_below(f);
+                if (r < FTGP_WAVE) list[r] = i;
+                mymask |= 1ull << k;
+            }
+            total += __popcll(f);
+        };
+        for (int k = 0; k < K; k += 2) {                            // two groups per trip: one address, two offsets
+            const float cur0 = p[k * FTGP_WAVE], prev0 = p[k * FTGP_WAVE - 1];
+            const float ad0 = fabsf(cur0 - prev0);
+            if (__any(ad0 >= T)) flagged(k, cur0, prev0, ad0);
+            if (k + 1 < K) {
+                const float cur1 = p[(k + 1) * FTGP_WAVE], prev1 = p[(k + 1) * FTGP_WAVE - 1];
+                const float ad1 = fabsf(cur1 - prev1);
+                if (__any(ad1 >= T)) flagged(k + 1, cur1, prev1, ad1);
             }
         }
     }
@@ -924,27 +954,35 @@ __device__ __forceinline__ void policy_disparity(const DeviceParams& P, float* _
         }
     }
     wave_lds_sync();
-    // argmax, first maximum (nidc.py:127): every lane scans its own samples (l, 64 + l, ...) in index order, lanes are merged with
-    // "the lower index wins ties"; sample 0 is the running maximum to begin with, whatever it is (a NaN there stays, like numpy's loop)
-    float bv = -INFINITY; int bi = 0x7fffffff;
-    if (lane == 0) { bv = proc[0]; bi = 0; }
-    for (int k = 0; k < K - 1; ++k) {                               // all of these are inside the window
-        const int i = k * FTGP_WAVE + lane;
-        const float x = proc[i];
-        if (x > bv) { bv = x; bi = i; }
-    }
+    // argmax, first maximum (nidc.py:127) = what the sequential loop "x > best" finds: every lane scans its own samples (l, 64 + l,
+    // ...) in index order and remembers the GROUP of its best one (a wave-uniform number: no index arithmetic per sample); then
+    // the wave's maximum, and the lowest index among the lanes that hold it.  Sample 0 is the running maximum to begin with,
+    // whatever it is: a NaN there stays (like numpy's loop), NaNs elsewhere never win.
+    float bv = -INFINITY; int bk = -1;
+    if (lane == 0) { bv = proc[0]; bk = 0; }
     {
-        const int i = (K - 1) * FTGP_WAVE + lane;
-        const float x = proc[i];
-        if (i < m && x > bv) { bv = x; bi = i; }
+        const float* __restrict__ p = proc + lane;
+        int k = 0;
+        for (; k + 1 < K - 1; k += 2) {                             // groups before the last lie inside the window
+            const float x0 = p[k * FTGP_WAVE], x1 = p[(k + 1) * FTGP_WAVE];
+            if (x0 > bv) { bv = x0; bk = k; }
+            if (x1 > bv) { bv = x1; bk = k + 1; }
+        }
+        if (k < K - 1) { const float x = p[k * FTGP_WAVE]; if (x > bv) { bv = x; bk = k; } }
+        const float x = p[(K - 1) * FTGP_WAVE];
+        if ((K - 1) * FTGP_WAVE + lane < m && x > bv) { bv = x; bk = K - 1; }
     }
-    #pragma unroll
-    for (int mm = 32; mm >= 1; mm >>= 1) {
-        const float ov = __shfl_xor(bv, mm, FTGP_WAVE);
-        const int oi = __shfl_xor(bi, mm, FTGP_WAVE);
-        if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
+    int bi;
+    {
+        // order-preserving integer image of the lane's maximum (-0 counts as +0, as it does for ">")
+        const uint32_t b = __float_as_uint(bv + 0.0f);
+        const uint32_t key = b ^ ((uint32_t)((int)b >> 31) | 0x80000000u);
+        const uint32_t top = wave_max_u32(key);
+        const uint32_t mine = (key == top && bk >= 0) ? (uint32_t)(bk * FTGP_WAVE + lane) : 0x7fffffffu;
+        bi = (int)wave_min_u32(mine);
+        const float b0 = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(bv)));
+        if (b0 != b0) bi = 0;                                       // sample 0 is a NaN: nothing is greater
     }
-    bi = __builtin_amdgcn_readfirstlane(bi);                        // lane 0's merge order is the sequential one
     double ang = ((double)bi - ((double)m / 2)) * rpp;              // nidc.py:112
     const double lim = 90.0 * (M_PI / 180.0);
     if (ang < -lim) ang = -lim;
