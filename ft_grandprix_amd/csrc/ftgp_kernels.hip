@@ -60,6 +60,16 @@ __device__ __forceinline__ int scan_window_first(int eighth) { return eighth & 3
 // step, so loads of constants (vehicle parameters, centre-line, ...) are never hoisted out of the loop -- hoisted, they
 // would stay live across the sweep and end up in scratch memory under the 64-VGPR budget.
 __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+s"(v)); return v; }
+// The parameter block as the scalar unit sees it: the kernel argument's copy in device memory, read through the constant address
+// space, i.e. with scalar loads -- wave-uniform values then reach their SGPRs without a vector instruction (out of LDS each one
+// costs a read and a v_readfirstlane, out of a spilled SGPR a v_readlane: the vector pipe is what this kernel is short of).
+// The pointer is made opaque once per step, so the loads stay inside the step instead of being hoisted and spilled.
+typedef const __attribute__((address_space(4))) DeviceParams* ScalarParams;
+__device__ __forceinline__ ScalarParams scalar_view(const DeviceParams* p)
+{
+    uint64_t a = (uint64_t)p; asm volatile("" : "+s"(a));
+    return (ScalarParams)a;
+}
 // the lane index, recomputed where it is used: values derived from it (per-lane addresses, selects) then stay local to the phase
 // that needs them instead of being hoisted in front of the step loop and carried -- spilled -- across the sweep
 __device__ __forceinline__ int lane_here() { int l = lane_id(); asm volatile("" : "+v"(l)); return l; }
@@ -73,6 +83,23 @@ __device__ __forceinline__ LdsOffsets lds_offsets(const DeviceParams& P)
     o.frame = sgpr(P.off_frame); o.steps = sgpr(P.off_steps); o.scan = sgpr(P.off_scan); o.list = sgpr(P.off_list); o.pool = sgpr(P.off_pool);
     o.k1 = sgpr(P.off_k1); o.cover = sgpr(P.off_cover); o.cpb = sgpr(P.cars_per_block);
     return o;
+}
+
+__device__ __forceinline__ LdsOffsets lds_offsets(ScalarParams G)
+{
+    LdsOffsets o;
+    o.params = G->off_params; o.veh = G->off_veh; o.path = G->off_path; o.ray = G->off_ray; o.cars = G->off_cars;
+    o.frame = G->off_frame; o.steps = G->off_steps; o.scan = G->off_scan; o.list = G->off_list; o.pool = G->off_pool;
+    o.k1 = G->off_k1; o.cover = G->off_cover; o.cpb = G->cars_per_block;
+    return o;
+}
+
+// what the on-device drivers need to know about the scan (wave-uniform)
+struct DriverShape { int n_rays, eighth, win_floats, cover_kmax; double rpp; };
+template <class PP> __device__ __forceinline__ DriverShape driver_shape(PP p)
+{
+    DriverShape d; d.n_rays = p->n_rays; d.eighth = p->eighth; d.win_floats = p->win_floats; d.cover_kmax = p->cover_kmax; d.rpp = p->rpp;
+    return d;
 }
 
 __device__ __forceinline__ Lds lds_view(const LdsOffsets& o, unsigned char* lds)
@@ -212,33 +239,42 @@ __device__ __forceinline__ void sweep_priority(bool second_half)
 }
 
 template <bool MULTI>
-__device__ __forceinline__ void lidar_pool(const DeviceParams& P, const Lds& L, const LidarFrame* frames, const PairCull* pairs, float* scan_rows, int* pool,
+__device__ __forceinline__ void lidar_pool(const DeviceParams& P, ScalarParams G, const Lds& L, const LidarFrame* frames, const PairCull* pairs, float* scan_rows, int* pool,
                                            int ncars_here, int ci0, bool scan_lds, bool second_half STAMP_ARG)
 {
     typedef const __attribute__((address_space(1))) unsigned char* global_u8;
     typedef __attribute__((address_space(1))) float* global_f32;
     typedef __attribute__((address_space(1))) unsigned char* global_u8w;
-    // wave-uniform constants of the sweep, pinned in SGPRs (they come out of the LDS parameter block, i.e. out of VGPRs)
-    const int R = sgpr(P.n_rays), total = ncars_here * R;
-    const int W = sgpr(P.width), H = sgpr(P.height), fstride = sgpr(P.fstride), stride = sgpr(P.ranges_stride);
-    const uint32_t plane256 = (uint32_t)sgpr((int)P.plane256), magic = (uint32_t)sgpr((int)P.ray_magic);
-    const int eighth = sgpr(P.eighth), win_floats = sgpr(P.win_floats);
-    const float isx = sgpr(P.inv_px_x_f), isy = sgpr(P.inv_px_y_f), eps = sgpr(P.snap_eps);
+    // wave-uniform constants of the sweep: scalar loads from the parameter block in device memory (scalar_view)
+    const int R = G->n_rays, total = ncars_here * R;
+    const int W = G->width, H = G->height, fstride = G->fstride, stride = G->ranges_stride;
+    const uint32_t plane256 = G->plane256, magic = G->ray_magic;
+    const int eighth = G->eighth, win_floats = G->win_floats;
+    const float isx = G->inv_px_x_f, isy = G->inv_px_y_f, eps = G->snap_eps;
     const float r0 = sgpr((float)L.veh->v.lidar_ring_radius);
-    const global_u8 field = (global_u8)uniform_ptr(P.field);
-    const global_f32 ranges = (global_f32)uniform_ptr(P.ranges) + (size_t)ci0 * stride;
+    const global_u8 field = (global_u8)G->field;
+    const global_f32 ranges = (global_f32)G->ranges + (size_t)ci0 * stride;
+    const int cars_per_env = G->cars_per_env;
     const int lane = lane_here();
     const bool all_safe = sgpr(pool[4]) == 0;        // every ray of this sweep starts on the image (frame_write): no test per ray
 
-    FtgpRay ray; ftgp_ray_park(ray, -1.0f);
-    float dxw = 0.0f, dyw = 0.0f;
-    float s_in = 0.0f;               // crossing time into the cell of the lane's latest lookup
+    // A lane's ray state means nothing until the lane is handed a ray (cj >= 0): a lane without one issues no load and stores
+    // nothing.  So the state starts out as whatever the registers hold (defined for the compiler, no instruction spent) --
+    // all but `result`, which ftgp_ray_init(assume_inside) leaves alone.
+    FtgpRay ray;
+    asm volatile("" : "=v"(ray.pum), "=v"(ray.pvm), "=v"(ray.dum), "=v"(ray.dvm), "=v"(ray.ivx), "=v"(ray.ivy), "=v"(ray.s));
+    asm volatile("" : "=v"(ray.ix), "=v"(ray.iy), "=v"(ray.offC), "=v"(ray.ax), "=v"(ray.ay));
+    ray.result = -1.0f;
+    float dxw, dyw;
+    float s_in;                      // crossing time into the cell of the lane's latest lookup
+    asm volatile("" : "=v"(dxw), "=v"(dyw), "=v"(s_in));
     int cj = -1;                     // (car slot << 16 | ray) of the ray this lane is marching (or has just finished); -1: none
     bool done = true;                // the lane's ray sits on its terminal cell (or the lane has none)
     bool pool_empty = false;         // wave-uniform
     bool hit = false;                // ... and that cell is a wall (not the ring)
     uint64_t live_mask = 0;          // lanes whose ray is still on its way (wave-uniform)
-    for (int round = 0; round < (1 << 20); ++round) {
+    for (int round = 0; round < (1 << 20); ) {      // (bounded: a safety net, counted on the scalar unit)
+        asm volatile("s_add_i32 %0, %0, 1" : "+s"(round) : : "scc");
         STAMP(ta);
         sweep_priority(second_half);
         // ---- finished rays: store the range ...
@@ -250,7 +286,7 @@ __device__ __forceinline__ void lidar_pool(const DeviceParams& P, const Lds& L, 
                 // mate out with a dot product: it can only be touched if it lies in front of the ray and within `cull` of its line.
                 // The exact box / puck tests run for what is left; results are unaffected by the cull.
                 const PairCull* mates = pairs + c * FTGP_PAIR_STRIDE;
-                for (int k = 0; k < P.cars_per_env; ++k) {
+                for (int k = 0; k < cars_per_env; ++k) {
                     const float4 q = *reinterpret_cast<const float4*>(mates + k);
                     const float al = fmaf(q.x, dxw, q.y * dyw);
                     if (al >= q.z) {
@@ -364,14 +400,15 @@ __device__ __forceinline__ void lidar_pool(const DeviceParams& P, const Lds& L, 
 
 // The scan window of a car (LDS row, see scan_window_first) to its row in HBM, by one wave: whole float4 groups -- 16 bytes per
 // lane, whole 128-byte lines per 8 lanes -- and single floats only at the two ragged ends of the window.
-__device__ __forceinline__ void window_flush(const DeviceParams& P, const float* __restrict__ row, int ci)
+template <class PP>
+__device__ __forceinline__ void window_flush(PP P, const float* __restrict__ row, int ci)
 {
     typedef __attribute__((address_space(1))) float* global_f32;
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(1))) f32x4* global_f32x4;
-    const int eighth = sgpr(P.eighth), n = sgpr(P.n_rays) - 2 * eighth, w0 = eighth & 3;
+    const int eighth = sgpr(P->eighth), n = sgpr(P->n_rays) - 2 * eighth, w0 = eighth & 3;
     // LDS float index q <-> HBM float index (eighth - w0) + q of the car's row; the window is q in [w0, w0 + n)
-    const global_f32 dst = (global_f32)uniform_ptr(P.ranges) + (size_t)ci * sgpr(P.ranges_stride) + (eighth - w0);
+    const global_f32 dst = (global_f32)uniform_ptr(P->ranges) + (size_t)ci * sgpr(P->ranges_stride) + (eighth - w0);
     const int lane = lane_here();
     const int g0 = w0 ? 1 : 0, g1 = (w0 + n) >> 2;                   // float4 groups [g0, g1) lie entirely inside the window
     for (int g = g0 + lane; g < g1; g += FTGP_WAVE) ((global_f32x4)dst)[g] = reinterpret_cast<const f32x4*>(row)[g];
@@ -863,16 +900,16 @@ __device__ __forceinline__ int cover_count(const float* __restrict__ thr, int km
 // Disparities are found on the unmodified scan (nidc.py:26-40) and extended in index order (nidc.py:86-105).  The cover
 // counts (one atan each) are prepared for up to 64 disparities at once, one per lane; the ordered pass re-reads the two
 // samples of each disparity and only recomputes the count when an earlier extension has changed them.
-__device__ __forceinline__ void policy_disparity(const DeviceParams& P, float* __restrict__ scan, CarCore* st, bool fast, int* __restrict__ list, const float* __restrict__ thr)
+__device__ __forceinline__ void policy_disparity(const DriverShape& D, float* __restrict__ scan, CarCore* st, bool fast, int* __restrict__ list, const float* __restrict__ thr)
 {
     const int lane = lane_here();
-    const int n = P.n_rays;
-    const double rpp = P.rpp;                                       // (2 pi) / n, nidc.py:121
-    const int eighth = P.eighth;                                    // int(n / 8), nidc.py:18
+    const int n = D.n_rays;
+    const double rpp = D.rpp;                                       // (2 pi) / n, nidc.py:121
+    const int eighth = D.eighth;                                    // int(n / 8), nidc.py:18
     const int m = n - 2 * eighth;
     float* __restrict__ proc = scan + scan_window_first(eighth);
-    const float range0 = scan[P.win_floats - 1];                    // ranges[0], fast.py:135
-    const int kmax = P.cover_kmax;                                  // thr = the cover-count thresholds of this driver (width = (car_width / 2) * (1 + 300 / 100), nidc.py:93)
+    const float range0 = scan[D.win_floats - 1];                    // ranges[0], fast.py:135
+    const int kmax = D.cover_kmax;                                  // thr = the cover-count thresholds of this driver (width = (car_width / 2) * (1 + 300 / 100), nidc.py:93)
     // Disparity flags (nidc.py:26-40, on the unmodified scan): lane l looks at samples l, 64 + l, 128 + l, ... (launch_steps()
     // guarantees m <= 64 * 64, i.e. K <= 64), so index order is (k, lane) order and a disparity's place in the ordered list is
     // the running total plus its rank among the flagged lanes of its k.  Disparities are rare: the common path of a k is two
@@ -1001,7 +1038,7 @@ __device__ __forceinline__ void policy_disparity(const DeviceParams& P, float* _
 }
 
 // evaluates the driver of car ci and stores the controls into its state record
-__device__ __forceinline__ void policy_apply(const DeviceParams& P, int policy, float* scan, CarCore* st, int ci, int64_t steps, int* list, const float* thr)
+__device__ __forceinline__ void policy_apply(const DeviceParams& P, const DriverShape& D, int policy, float* scan, CarCore* st, int ci, int64_t steps, int* list, const float* thr)
 {
     const bool lane0 = lane_id() == 0;
     if (st->finished) {                                             // finished cars get the null driver (custom.py:1446)
@@ -1011,7 +1048,7 @@ __device__ __forceinline__ void policy_apply(const DeviceParams& P, int policy, 
     switch (policy) {
     case FTGP_POLICY_LOBOTOMY: if (lane0) { st->u_speed = 0.0; st->u_steer = 0.0; } break;   // lobotomy.py:2-3
     case FTGP_POLICY_NIDC:
-    case FTGP_POLICY_FAST: policy_disparity(P, scan, st, policy == FTGP_POLICY_FAST, list, thr); break;
+    case FTGP_POLICY_FAST: policy_disparity(D, scan, st, policy == FTGP_POLICY_FAST, list, thr); break;
     case FTGP_POLICY_RANDOM: {
         uint64_t h = splitmix64(P.seed + (uint64_t)((long)P.env_base * P.cars_per_env + ci) * 0x9E3779B97F4A7C15ull);
         h = splitmix64(h ^ (uint64_t)steps);
@@ -1183,44 +1220,53 @@ __global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(cons
 #endif
     for (int it = 0; it < n_steps; ++it) {
         STAMP(t0);
-        // every step sees the parameter block and the LDS arrays through fresh, opaque offsets (see opaque())
-        const DeviceParams& P = *reinterpret_cast<const DeviceParams*>(lds + opaque(off.params));
-        const Lds L = lds_view(off, lds);
+        // Each phase of a step fetches what it needs of the parameter block with scalar loads (scalar_view) and sees the LDS arrays
+        // through fresh offsets: nothing of this is carried -- spilled -- from step to step or across the other phase.
         const int par = it & 1;
-        const int win_floats = sgpr(P.win_floats);
-        LidarFrame* frames = L.frame + par * cpb;
-        LidarFrame* next_frames = L.frame + (par ^ 1) * cpb;
-        float* scan_now = L.scan + par * cpb * win_floats;
-        float* scan_prev = L.scan + (par ^ 1) * cpb * win_floats;
+        if (wave < ncars_here) {         // drivers (and, for the wave that delivers last, dynamics)
+            const ScalarParams G = scalar_view(Pg);
+            const LdsOffsets off = lds_offsets(G);
+            const DeviceParams& P = *reinterpret_cast<const DeviceParams*>(lds + off.params);
+            const Lds L = lds_view(off, lds);
+            const int win_floats = G->win_floats;
+            LidarFrame* next_frames = L.frame + (par ^ 1) * cpb;
+            float* scan_prev = L.scan + (par ^ 1) * cpb * win_floats;
 #ifndef FTGP_NO_PRIO
-        // the driver -> dynamics chain is the latency-critical path of a step and a small share of its instructions: let it issue first
-        if (wave < ncars_here) __builtin_amdgcn_s_setprio(3);
+            // the driver -> dynamics chain is the latency-critical path of a step and a small share of its instructions: let it issue first
+            __builtin_amdgcn_s_setprio(3);
 #endif
-        for (int c = wave; c < ncars_here; c += nwaves) {
-            if (need_scan && it > 0) window_flush(P, scan_prev + c * win_floats, ci0 + c);     // the previous sweep's window, before the driver edits it
-            if (policy != FTGP_POLICY_HOST) policy_apply(P, policy, scan_prev + c * win_floats, L.cars + c, ci0 + c, L.steps[c], L.list + wave * FTGP_WAVE, L.cover);
-            wave_lds_sync();
-            // "my controls are in LDS" -> the wave that counts last reads every car's controls: release on this side (the
-            // fence of wave_lds_sync() + the RMW), acquire on the reader's (the RMW + the fence below), workgroup scope
-            int n = 0;
-            if (lane == 0) n = __hip_atomic_fetch_add(L.pool + 2 + par, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-            n = __builtin_amdgcn_readfirstlane(n);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            STAMP(t1); STAMP_ADD(0, t1 - t0);
-            if (n == ncars_here - 1) {            // every driver of the workgroup has delivered its controls
-                if (lane == 0) { L.pool[par ^ 1] = 0; L.pool[2 + (par ^ 1)] = 0; }     // the next step's counters (idle during this step)
+            for (int c = wave; c < ncars_here; c += nwaves) {
+                if (need_scan && it > 0) window_flush(G, scan_prev + c * win_floats, ci0 + c);     // the previous sweep's window, before the driver edits it
+                if (policy != FTGP_POLICY_HOST) policy_apply(P, driver_shape(G), policy, scan_prev + c * win_floats, L.cars + c, ci0 + c, L.steps[c], L.list + wave * FTGP_WAVE, L.cover);
+                wave_lds_sync();
+                // "my controls are in LDS" -> the wave that counts last reads every car's controls: release on this side (the
+                // fence of wave_lds_sync() + the RMW), acquire on the reader's (the RMW + the fence below), workgroup scope
+                int n = 0;
+                if (lane == 0) n = __hip_atomic_fetch_add(L.pool + 2 + par, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+                n = __builtin_amdgcn_readfirstlane(n);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                STAMP(t1); STAMP_ADD(0, t1 - t0);
+                if (n == ncars_here - 1) {            // every driver of the workgroup has delivered its controls
+                    if (lane == 0) { L.pool[par ^ 1] = 0; L.pool[2 + (par ^ 1)] = 0; }     // the next step's counters (idle during this step)
 #ifndef FTGP_ABLATE_K1
-                dynamics_lanes<MULTI>(P, L, next_frames, L.pairs + (par ^ 1) * cpb * FTGP_PAIR_STRIDE, L.pool + 4 + (par ^ 1), ncars_here, ci0);
+                    dynamics_lanes<MULTI>(P, L, next_frames, L.pairs + (par ^ 1) * cpb * FTGP_PAIR_STRIDE, L.pool + 4 + (par ^ 1), ncars_here, ci0);
 #endif
-                STAMP(t2); STAMP_ADD(2, t2 - t1); STAMP_ADD(7, 1);
+                    STAMP(t2); STAMP_ADD(2, t2 - t1); STAMP_ADD(7, 1);
+                }
             }
-        }
 #ifndef FTGP_NO_PRIO
-        __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_setprio(0);
 #endif
+        }
         STAMP(t3);
 #ifndef FTGP_ABLATE_K2
-        lidar_pool<MULTI>(P, L, frames, L.pairs + par * cpb * FTGP_PAIR_STRIDE, scan_now, L.pool + par, ncars_here, ci0, need_scan, second_half STAMP_PASS);
+        {
+            const ScalarParams G = scalar_view(Pg);
+            const LdsOffsets off = lds_offsets(G);
+            const DeviceParams& P = *reinterpret_cast<const DeviceParams*>(lds + off.params);
+            const Lds L = lds_view(off, lds);
+            lidar_pool<MULTI>(P, G, L, L.frame + par * cpb, L.pairs + par * cpb * FTGP_PAIR_STRIDE, L.scan + par * cpb * G->win_floats, L.pool + par, ncars_here, ci0, need_scan, second_half STAMP_PASS);
+        }
 #endif
         STAMP(t4);
         __syncthreads();
@@ -1232,11 +1278,12 @@ __global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(cons
     if (lane == 0) for (int q = 0; q < 12; ++q) atomicAdd(&ftgp_stamps[q], stamp_acc[q]);
 #endif
     const DeviceParams& P = P0;
-    const Lds L = lds_view(off, lds);
+    const LdsOffsets off_end = lds_offsets(scalar_view(Pg));
+    const Lds L = lds_view(off_end, lds);
     for (int c = wave; c < ncars_here; c += nwaves) {
         const int ci = ci0 + c;
         if (need_scan && n_steps > 0)          // the last sweep's window
-            window_flush(P, L.scan + (((n_steps - 1) & 1) * cpb + c) * P.win_floats, ci);
+            window_flush(&P, L.scan + (((n_steps - 1) & 1) * cpb + c) * P.win_floats, ci);
         if (lane < (int)(sizeof(CarCore) / 4))
             reinterpret_cast<uint32_t*>(static_cast<CarCore*>(&P.cars[ci]))[lane] = reinterpret_cast<const uint32_t*>(L.cars + c)[lane];
         if (lane == 0 && ci % P.cars_per_env == 0) P.steps[ci / P.cars_per_env] = L.steps[c];
@@ -1272,7 +1319,7 @@ __global__ void __launch_bounds__(256) ftgp_policy_kernel(DeviceParams P, int po
     if (lane < (int)(sizeof(CarCore) / 4))
         reinterpret_cast<uint32_t*>(st)[lane] = reinterpret_cast<const uint32_t*>(static_cast<const CarCore*>(&P.cars[ci]))[lane];
     wave_lds_sync();
-    policy_apply(P, policy, scan, st, ci, P.steps[ci / P.cars_per_env], list, P.cover_thr + (policy == FTGP_POLICY_FAST ? P.cover_kmax + 1 : 0));
+    policy_apply(P, driver_shape(&P), policy, scan, st, ci, P.steps[ci / P.cars_per_env], list, P.cover_thr + (policy == FTGP_POLICY_FAST ? P.cover_kmax + 1 : 0));
     wave_lds_sync();
     if (lane == 0) {
         P.cars[ci].u_speed = st->u_speed; P.cars[ci].u_steer = st->u_steer; P.cars[ci].last_steer = st->last_steer;
