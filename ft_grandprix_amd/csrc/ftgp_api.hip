@@ -499,6 +499,8 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
         const double cx = std::max(fabs(v.box_xmin), fabs(v.box_xmax)), cy = std::max(fabs(v.box_ymin), fabs(v.box_ymax));
         const double rmax = std::max(sqrt(cx * cx + cy * cy), sqrt(v.lidar_x * v.lidar_x + v.lidar_y * v.lidar_y) + v.lidar_ring_radius);
         vl.cull_radius = (float)(1.1 * rmax);
+        vl.box_xmin_f = (float)v.box_xmin; vl.box_xmax_f = (float)v.box_xmax; vl.box_ymin_f = (float)v.box_ymin; vl.box_ymax_f = (float)v.box_ymax;
+        vl.lidar_x_f = (float)v.lidar_x; vl.lidar_y_f = (float)v.lidar_y; vl.ring_radius_f = (float)v.lidar_ring_radius;
         memcpy(vimg.data(), &vl, sizeof vl);
         CREATE_TRY(hipMalloc(&e->d_veh, vimg.size()));
         CREATE_TRY(hipMemcpy(e->d_veh, vimg.data(), vimg.size(), hipMemcpyHostToDevice));

@@ -100,6 +100,8 @@ struct VehLds {
     FtgpVehicle v;
     double wheel_load[4];
     float cull_radius, pad;       // every part of a car that a ray can see lies within this distance of the car's origin
+    // binary32 of the constants the inter-vehicle ray test uses (the conversions the specification makes per test, made once)
+    float box_xmin_f, box_xmax_f, box_ymin_f, box_ymax_f, lidar_x_f, lidar_y_f, ring_radius_f, pad_f;
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -126,48 +126,6 @@ __device__ __forceinline__ Lds lds_view(const LdsOffsets& o, unsigned char* lds)
 // =============================================================================================
 // K2: LiDAR
 // =============================================================================================
-// Ray against another car: chassis box (slab test) and LiDAR puck (circle), binary32.
-__device__ __forceinline__ float ray_vs_car(const FtgpVehicle& v, const LidarFrame* b, double lcx, double lcy, float dxw, float dyw)
-{
-    const float r0 = (float)v.lidar_ring_radius;
-    float best = INFINITY;
-    const double bqw = b->qw, bqz = b->qz;
-    const double cb = 1.0 - 2.0 * (bqz * bqz), sb = 2.0 * (bqw * bqz);
-    const float relx = (float)(lcx - b->x), rely = (float)(lcy - b->y);
-    const float ox = fmaf(dxw, -r0, relx), oy = fmaf(dyw, -r0, rely);
-    const float cbf = (float)cb, sbf = (float)sb;
-    const float lx = fmaf(cbf, ox, sbf * oy), ly = fmaf(cbf, oy, -(sbf * ox));
-    const float ldx = fmaf(cbf, dxw, sbf * dyw), ldy = fmaf(cbf, dyw, -(sbf * dxw));
-    {
-        const float xmin = (float)v.box_xmin, xmax = (float)v.box_xmax, ymin = (float)v.box_ymin, ymax = (float)v.box_ymax;
-        float tmin = -INFINITY, tmax = INFINITY; bool miss = false;
-        if (ldx != 0.0f) {
-            const float inv = 1.0f / ldx; const float t1 = (xmin - lx) * inv, t2 = (xmax - lx) * inv;
-            tmin = fmaxf(tmin, fminf(t1, t2)); tmax = fminf(tmax, fmaxf(t1, t2));
-        } else if (lx < xmin || lx > xmax) miss = true;
-        if (ldy != 0.0f) {
-            const float inv = 1.0f / ldy; const float t1 = (ymin - ly) * inv, t2 = (ymax - ly) * inv;
-            tmin = fmaxf(tmin, fminf(t1, t2)); tmax = fminf(tmax, fmaxf(t1, t2));
-        } else if (ly < ymin || ly > ymax) miss = true;
-        if (!miss && tmax >= fmaxf(tmin, 0.0f)) {
-            const float t = tmin > 0.0f ? tmin : 0.0f;
-            if (t < best) best = t;
-        }
-    }
-    {
-        const float px = lx - (float)v.lidar_x, py = ly - (float)v.lidar_y;
-        const float bq = fmaf(px, ldx, py * ldy);
-        const float cq = fmaf(px, px, py * py) - r0 * r0;
-        const float disc = fmaf(bq, bq, -cq);
-        if (disc >= 0.0f) {
-            float t = -bq - sqrtf(disc);
-            if (t < 0.0f) t = (cq < 0.0f) ? 0.0f : INFINITY;
-            if (t < best) best = t;
-        }
-    }
-    return best;
-}
-
 // The sweep of one step for all cars of the workgroup, executed by every wave.  Rangefinder geometry:
 // template/mushr.em.xml:98-117 -- ray j leaves the ring at centre - 0.03*dir_j, dir_j = R(yaw) * (sin phi_j, -cos phi_j);
 // j = 0 is the rear, CCW.  Values replace data.sensordata[vehicle_state.sensors] (custom.py:1395).
@@ -204,6 +162,52 @@ __device__ __forceinline__ void rcp_abs2(float x, float y, float& rx, float& ry)
         p = oddx ? zx : p; q = oddy ? zy : q;
     }
     rx = p; ry = q;
+}
+
+// Ray against another car: chassis box (slab test) and LiDAR puck (circle), binary32 -- the specification's arithmetic with
+// everything that does not depend on the ray taken from where it already exists: (bx, by) = mate's origin - my LiDAR centre is
+// the pair record's (its negation is the specification's (float)(centre - origin): binary64 subtraction and the conversion
+// are odd functions), the mate's heading in binary32 is its LiDAR frame's, the vehicle constants in binary32 are VehLds',
+// and the two IEEE reciprocals are rcp_abs2's with the sign put back.
+__device__ __forceinline__ float ray_vs_car(const VehLds* V, const LidarFrame* b, float bx, float by, float dxw, float dyw)
+{
+    const float r0 = V->ring_radius_f;
+    float best = INFINITY;
+    const float relx = -bx, rely = -by;
+    const float ox = fmaf(dxw, -r0, relx), oy = fmaf(dyw, -r0, rely);
+    const float cbf = b->chf, sbf = b->shf;
+    const float lx = fmaf(cbf, ox, sbf * oy), ly = fmaf(cbf, oy, -(sbf * ox));
+    const float ldx = fmaf(cbf, dxw, sbf * dyw), ldy = fmaf(cbf, dyw, -(sbf * dxw));
+    {
+        const float xmin = V->box_xmin_f, xmax = V->box_xmax_f, ymin = V->box_ymin_f, ymax = V->box_ymax_f;
+        float tmin = -INFINITY, tmax = INFINITY; bool miss = false;
+        float ax, ay;
+        rcp_abs2(ldx, ldy, ax, ay);
+        if (ldx != 0.0f) {
+            const float inv = copysignf(ax, ldx); const float t1 = (xmin - lx) * inv, t2 = (xmax - lx) * inv;
+            tmin = fmaxf(tmin, fminf(t1, t2)); tmax = fminf(tmax, fmaxf(t1, t2));
+        } else if (lx < xmin || lx > xmax) miss = true;
+        if (ldy != 0.0f) {
+            const float inv = copysignf(ay, ldy); const float t1 = (ymin - ly) * inv, t2 = (ymax - ly) * inv;
+            tmin = fmaxf(tmin, fminf(t1, t2)); tmax = fminf(tmax, fmaxf(t1, t2));
+        } else if (ly < ymin || ly > ymax) miss = true;
+        if (!miss && tmax >= fmaxf(tmin, 0.0f)) {
+            const float t = tmin > 0.0f ? tmin : 0.0f;
+            if (t < best) best = t;
+        }
+    }
+    {
+        const float px = lx - V->lidar_x_f, py = ly - V->lidar_y_f;
+        const float bq = fmaf(px, ldx, py * ldy);
+        const float cq = fmaf(px, px, py * py) - r0 * r0;
+        const float disc = fmaf(bq, bq, -cq);
+        if (disc >= 0.0f) {
+            float t = -bq - sqrtf(disc);
+            if (t < 0.0f) t = (cq < 0.0f) ? 0.0f : INFINITY;
+            if (t < best) best = t;
+        }
+    }
+    return best;
 }
 
 // diagnostic build only (tools/stamps.sh): per-phase shader-clock totals over all workgroups and steps; never in the product
@@ -293,7 +297,7 @@ __device__ __forceinline__ void lidar_pool(const DeviceParams& P, ScalarParams G
                         const float cull = L.veh->cull_radius;
                         if (r >= 0.0f && (al + r0) - cull > r) continue;             // the mate lies beyond the wall hit
                         const LidarFrame* me = frames + c;
-                        const float rc = ray_vs_car(L.veh->v, frames + me->slot0 + k, me->lcx, me->lcy, dxw, dyw);
+                        const float rc = ray_vs_car(L.veh, frames + me->slot0 + k, q.x, q.y, dxw, dyw);
                         if (rc < INFINITY && (r < 0.0f || rc < r)) r = rc;
                     }
                 }
