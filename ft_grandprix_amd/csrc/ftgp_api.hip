@@ -894,6 +894,14 @@ int ftgp_debug_stamps(unsigned long long* out)
     unsigned long long z[16] = { 0 };
     return hipMemcpyToSymbol(HIP_SYMBOL(ftgp_stamps), z, sizeof z) == hipSuccess ? 0 : -1;
 }
+#endif
+#if defined(FTGP_STAMPS) || defined(FTGP_WG_TIMES)
+int ftgp_debug_set_wg_groups(const int* groups, int n_blocks)      // groups == nullptr: identity
+{
+    std::vector<int> g(8192, 0);
+    if (groups) { for (int i = 0; i < n_blocks && i < 8191; ++i) g[i] = groups[i]; g[8191] = 1; }
+    return hipMemcpyToSymbol(HIP_SYMBOL(ftgp_wg_group), g.data(), sizeof(int) * 8192) == hipSuccess ? 0 : -1;
+}
 int ftgp_debug_wg_times(unsigned long long* out, int n_blocks)
 {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(ftgp_wg_times), sizeof(unsigned long long) * 4 * (size_t)n_blocks) == hipSuccess ? 0 : -1;

@@ -210,10 +210,19 @@ __device__ __forceinline__ float ray_vs_car(const VehLds* V, const LidarFrame* b
     return best;
 }
 
-// diagnostic build only (tools/stamps.sh): per-phase shader-clock totals over all workgroups and steps; never in the product
+// diagnostic builds only, never in the product.  -DFTGP_STAMPS (tools/stamps.sh): per-phase shader-clock totals over all
+// workgroups and steps (their atomics at the end of a launch cost about a millisecond: long launches only) + what
+// -DFTGP_WG_TIMES alone gives: per workgroup the 100-MHz wall clock at entry and at exit, HW_ID, XCC_ID (tools/wg_spread.py),
+// and a table that says which group of cars a workgroup slot takes (tools/wg_pairing.py; [8191] != 0 switches it on).
+#if defined(FTGP_STAMPS) && !defined(FTGP_WG_TIMES)
+#define FTGP_WG_TIMES
+#endif
+#ifdef FTGP_WG_TIMES
+__device__ unsigned long long ftgp_wg_times[8192][4];
+__device__ int ftgp_wg_group[8192];
+#endif
 #ifdef FTGP_STAMPS
 __device__ unsigned long long ftgp_stamps[16];
-__device__ unsigned long long ftgp_wg_times[8192][4];      // per workgroup: 100-MHz wall clock at entry and at exit, HW_ID, XCC_ID (tools/wg_spread.py)
 #define STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
 #define STAMP_ADD(slot, dt) stamp_acc[slot] += (unsigned long long)(dt)
 #define STAMP_ARG , unsigned long long* stamp_acc
@@ -1162,7 +1171,7 @@ __global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(cons
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = __builtin_amdgcn_readfirstlane(blockDim.x >> 6);
-#ifdef FTGP_STAMPS
+#ifdef FTGP_WG_TIMES
     if (threadIdx.x == 0 && blockIdx.x < 8192) {
         ftgp_wg_times[blockIdx.x][0] = __builtin_amdgcn_s_memrealtime();
         unsigned hw, xcc;
@@ -1182,7 +1191,11 @@ __global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(cons
     __syncthreads();
     const LdsOffsets off = lds_offsets(P0);
     const int cpb = sgpr(P0.cars_per_block);
+#ifdef FTGP_WG_TIMES
+    const int ci0 = (ftgp_wg_group[8191] && blockIdx.x < 8191 ? __builtin_amdgcn_readfirstlane(ftgp_wg_group[blockIdx.x]) : (int)blockIdx.x) * cpb;
+#else
     const int ci0 = (int)blockIdx.x * cpb;
+#endif
     const int ncars_here = min(cpb, sgpr(P0.n_cars) - ci0);
     const bool second_half = (((int)blockIdx.x / max(1, sgpr(P0.n_cu))) & 1) != 0;      // see sweep_priority(): workgroups b and b + n_cu share a CU in the first dispatch wave
     const bool need_scan = (policy == FTGP_POLICY_NIDC || policy == FTGP_POLICY_FAST);
@@ -1296,7 +1309,7 @@ __global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(cons
         __syncthreads();
         launch_metrics(P, L.cars, L.steps, ncars_here, ci0, lds + P.off_scan);
     }
-#ifdef FTGP_STAMPS
+#ifdef FTGP_WG_TIMES
     __syncthreads();
     if (threadIdx.x == 0 && blockIdx.x < 8192) ftgp_wg_times[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
 #endif
