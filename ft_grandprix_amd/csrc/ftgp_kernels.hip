@@ -131,7 +131,7 @@ __device__ __forceinline__ Lds lds_view(const LdsOffsets& o, unsigned char* lds)
 // j = 0 is the rear, CCW.  Values replace data.sensordata[vehicle_state.sensors] (custom.py:1395).
 //
 // Scheduling: pool index g = car slot * n_rays + j.  A lane marches one ray at a time with ftgp_ray_step/fix/commit (a
-// finished ray idles on its terminal cell, so the loop body has no active-lane predication); as soon as FTGP_REFILL lanes
+// finished ray idles -- no load, nothing held: the loop body has no active-lane predication); as soon as FTGP_REFILL lanes
 // of the wave are finished, their ranges are stored and they take the next rays of the pool together (one LDS atomic
 // per refill, rank among the free lanes via ballot/popcount).  Which lane marches which ray has no influence on any result.
 #ifndef FTGP_PAD_ASM
@@ -264,7 +264,7 @@ __device__ __forceinline__ void lidar_pool(const DeviceParams& P, ScalarParams G
     const uint32_t plane256 = G->plane256, magic = G->ray_magic;
     const int eighth = G->eighth, win_floats = G->win_floats;
     const float isx = G->inv_px_x_f, isy = G->inv_px_y_f, eps = G->snap_eps;
-    const float r0 = sgpr((float)L.veh->v.lidar_ring_radius);
+    const float r0 = sgpr(L.veh->ring_radius_f);
     const global_u8 field = (global_u8)G->field;
     const global_f32 ranges = (global_f32)G->ranges + (size_t)ci0 * stride;
     const int cars_per_env = G->cars_per_env;
@@ -353,7 +353,7 @@ __device__ __forceinline__ void lidar_pool(const DeviceParams& P, ScalarParams G
                 const float pv = fmaf(dv, -r0, f4.y);
                 float ivx, ivy;
                 rcp_abs2(du, dv, ivx, ivy);
-                // result stays -1 (ftgp_ray_park above); offsets and strides of the ray's sector come out of the LDS table
+                // `result` stays as set at the top of the sweep (-1); offsets and strides of the ray's sector come out of the LDS table
                 ftgp_ray_init(ray, pu, pv, du, dv, ivx, ivy, W, H, fstride, plane256, true, &P.sector_tab[0][0]);
                 if (!all_safe) {         // wave-uniform, rare: some car of the workgroup is near the image edge, off it, or has finished
                     ftgp_ray_park_if_outside(ray, pu, pv, W, H);
