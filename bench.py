@@ -221,11 +221,22 @@ def main():
                 err = str(exc)
             oks = rdzv.allgather_bytes(b"\x01" if err is None else b"\x00" + err.encode()[:300])
             bad = [(r, o[1:].decode(errors="replace")) for r, o in enumerate(oks) if o[:1] != b"\x01"]
-            if bad:                   # RCCL was requested and is not usable: fail loudly on every rank, no silent fallback
+            if bad:
+                # RCCL was requested and is not usable.  Every rank knows (the statuses were exchanged), so all take the same
+                # branch.  A bootstrap that STALLED may still hold the handle: stop, loudly.  A bootstrap that RETURNED an
+                # error leaves the handle usable: the 64-byte metrics record then travels over the host rendezvous instead
+                # -- said on stderr and in the JSON line, never silently; the hot path (no collective) is unaffected.
                 if rank == 0:
                     print(f"bench.py: the RCCL communicator could not be set up: {bad}", file=sys.stderr)
-                rdzv.close()
-                os._exit(3)           # a stalled RCCL thread may still hold the handle: do not wait for it
+                if any("did not return in time" in why for _, why in bad) or os.environ.get("FTGP_BENCH_RCCL_REQUIRED"):
+                    rdzv.close()
+                    os._exit(3)       # do not wait for a stalled RCCL thread
+                host_gather = True
+                collective = ("host TCP gather -- FALLBACK: ncclCommInitRank failed on rank(s) "
+                              + ", ".join(f"{r} ({why[:120]})" for r, why in bad))
+                if rank == 0:
+                    print("bench.py: falling back to the host TCP gather for the metrics record (set FTGP_BENCH_RCCL_REQUIRED=1 to "
+                          "make this fatal)", file=sys.stderr)
 
     def gather():
         if host_gather:

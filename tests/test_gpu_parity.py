@@ -431,6 +431,26 @@ def test_gpu_shards_reproduce_the_monolithic_batch(product):
         assert tot == {**ref, "ranks": 2}
 
 
+def test_bench_two_ranks_rccl_refusal_is_loud_and_labelled(product):
+    """`bench.py --gpus 2` on the box's one GPU WITHOUT the rehearsal switch: RCCL refuses a two-rank communicator on one device
+    (ncclCommInitRank returns "invalid usage"), every rank learns of it, and the metrics record travels over the host rendezvous
+    instead -- said on stderr and in the JSON line; with FTGP_BENCH_RCCL_REQUIRED=1 the same refusal is fatal (rc 3)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "FTGP_BENCH_COLLECTIVE")}
+    env["FTGP_RCCL_INIT_TIMEOUT"] = "90"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--envs-per-gpu", "64", "--rays", "90"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "could not be set up" in p.stderr and "falling back to the host TCP gather" in p.stderr
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["metrics_allgather"]["ranks"] == 2
+    assert d["metrics_allgather"]["collective"].startswith("host TCP gather -- FALLBACK: ncclCommInitRank failed")
+    env["FTGP_BENCH_RCCL_REQUIRED"] = "1"
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400)
+    assert p.returncode == 3 and "could not be set up" in p.stderr
+
+
 def test_rccl_communicator_single_rank(product):
     """C1 through the real RCCL entry points (ncclGetUniqueId / ncclCommInitRank / ncclAllGather) with world_size 1."""
     t = load_track("circle")
