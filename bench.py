@@ -278,8 +278,8 @@ def main():
                 "rays_per_s": args.envs_per_gpu * args.cars * args.rays * args.steps / kernel_s,
                 # `bound` names the roofline SURVEY.md 8d prescribes for this path (its algorithmic bytes against HBM); what actually
                 # limits the kernel is vector-instruction issue, far above the HBM ridge -- see `valu`
-                "limiter": "vector-instruction issue: the SIMDs' vector pipes are busy ~100 % of the time (valu.busy_frac) with "
-                           "instructions that cost 2-4 cycles each; HBM traffic is a few percent of peak"}
+                "limiter": "vector-instruction issue: the SIMDs' vector pipes are busy more than 90 % of the time (valu.busy_frac) with "
+                           "instructions that cost 2-4 cycles each; the measured fabric traffic is a sixth of the HBM peak"}
         tr = committed_counters("traffic", args.envs_per_gpu, args.rays, args.cars, args.policy, args.track)
         if tr is not None:
             # HBM bytes per launch = the committed PMC figure per env-step (FETCH_SIZE x2 + WRITE_SIZE, separate passes) scaled to this launch
