@@ -3,7 +3,9 @@
 
 A "step" is one pass of the hot path over the whole batch: driver (fast, on device) -> LiDAR sweep written
 to HBM -> integrate -> lap progress, for every env.  All inputs are resident in HBM before the timed region;
-the K timed steps run as ONE persistent launch (the state stays in LDS between steps).
+the K timed steps run as ONE persistent launch (the state stays in LDS between steps).  A launch of few steps is far shorter than
+the clock differences between boxes, so `--repeats` such launches are timed one by one (default: enough of them for about 20 ms of
+kernel time) and the MEDIAN launch is what `value` and `ms_per_step` report (`repeats`, best and worst are in the line).
 
     python bench.py --gpus N --steps K --warmup W
 
@@ -11,10 +13,12 @@ N > 1: one process per GPU.  Launched by `python -m torch.distributed.run --nnod
 --gpus N` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the env), or, when no launcher set WORLD_SIZE, bench.py starts
 its own N ranks.  The host path is torch-free: rendezvous, barrier and the max-over-ranks timing go over
 ft_grandprix_amd.dist.Rendezvous (TCP on MASTER_ADDR); envs shard across ranks with no data-path collective (weak scaling:
-4096 envs per GPU); the only exchange is the end-of-launch metrics all-gather over RCCL, issued on a side stream.
+4096 envs per GPU); the only exchange is the end-of-launch metrics all-gather over RCCL, issued on a side stream behind launch k
+and collected while launch k + 1 runs (ftgp_metrics_allgather_begin / _end, ft_grandprix_amd.dist.run_timed).
 Rank 0 prints ONE JSON line.
 """
 import argparse
+import glob
 import hashlib
 import json
 import os
@@ -23,6 +27,8 @@ import subprocess
 import sys
 import threading
 import time
+
+import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -35,7 +41,7 @@ ALGO_BYTES_PER_ENV_STEP = lambda n_rays, cars: cars * (4 * n_rays + 832)   # SUR
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_MEASURED_COPY_GBS = 6290.0
 N_SIMD = 256 * 4               # MI355X: 256 CUs x 4 SIMD-32; a wave64 VALU instruction issues over 2 cycles on one SIMD
-PROFILE_DIRS = [os.path.join(ROOT, "profiles", d) for d in ("round3", "round2")]     # newest first
+PROFILE_DIRS = [os.path.join(ROOT, "profiles", d) for d in ("round4", "round3", "round2")]     # newest first
 
 
 def kernel_source_sha():
@@ -52,7 +58,6 @@ def committed_counters(prefix, n_envs, n_rays, cars, policy, track="track"):
     """The newest counter summary (`<prefix>_*.json`) committed under profiles/roundN by tools/collect_profile.py (rocprofv3 --pmc,
     separate passes) that was measured on this configuration.  The counters cannot be read from inside this process; `stale`
     says whether the kernel sources have changed since."""
-    import glob
     for d in PROFILE_DIRS:
         for p in sorted(glob.glob(os.path.join(d, prefix + "_*.json"))):
             t = json.load(open(p))
@@ -171,7 +176,9 @@ def main():
     ap.add_argument("--track", default="track")
     ap.add_argument("--policy", default="fast")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--repeats", type=int, default=1, help="timed launches of K steps (the best is reported in ms_per_step_best)")
+    ap.add_argument("--repeats", type=int, default=0, help="timed launches of K steps each, timed one by one; the median is reported "
+                                                           "(0 = as many as make about 20 ms of kernel time, at most 31)")
+    ap.add_argument("--lidar", default="rangefinder", choices=("rangefinder", "fakelidar"))
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -192,7 +199,7 @@ def main():
     seed = 1234
     # rank r owns envs [r * envs_per_gpu, (r + 1) * envs_per_gpu) of one world-sized batch (BASELINE.json configs[3] at N = 8)
     env = capi.Env(lib, track, n_envs=args.envs_per_gpu, cars_per_env=args.cars, n_rays=args.rays, spawn_mode=1,
-                   seed=seed, device_id=local_rank % n_dev, env_base=rank * args.envs_per_gpu)
+                   seed=seed, device_id=local_rank % n_dev, env_base=rank * args.envs_per_gpu, lidar_mode=args.lidar)
     collective = "none (1 rank)"
     host_gather = False
     if world > 1:
@@ -238,34 +245,38 @@ def main():
                     print("bench.py: falling back to the host TCP gather for the metrics record (set FTGP_BENCH_RCCL_REQUIRED=1 to "
                           "make this fatal)", file=sys.stderr)
 
-    def gather():
-        if host_gather:
-            return rdzv.all_gather(env.metrics_local())
-        return env.metrics_allgather()
+    # The exchange of launch k's record overlaps launch k + 1 (ftdist.run_timed).  Over RCCL it rides the side stream; over the
+    # host rendezvous a worker thread gathers on a connection set of its own (the main one carries the barriers meanwhile).
+    rdzv_x = None
+    if host_gather:
+        rdzv_x = ftdist.Rendezvous.from_env(channel="x")
+        exchange = ftdist.HostExchange(env, rdzv_x)
+    else:
+        exchange = ftdist.DeviceExchange(env)
 
     def barrier():
         if rdzv is not None:
             rdzv.barrier()
 
-    # warmup (untimed)
-    env.rollout(args.policy, args.warmup)
-    gather()
-    env.last_kernel_ms()
+    repeats = args.repeats
+    if repeats <= 0:           # a launch of few steps is shorter than anything a wall clock compares across boxes: time several
+        repeats = max(1, min(31, int(20.0 / max(args.steps * 0.03 * args.cars, 1e-3) + 0.999)))
+        repeats += 1 - repeats % 2                                   # odd: the median is a launch that happened
 
-    best_ms = None
+    # warmup (untimed); its exchange is begun here and collected beside the first timed launch
+    env.rollout(args.policy, args.warmup)
+    env.last_kernel_ms()
+    exchange.begin()
+
+    timed = ftdist.run_timed(env, args.policy, args.steps, repeats, exchange, barrier)      # EXACTLY K steps per launch
+    metrics = timed["records"]
+    walls, kmss = np.asarray(timed["wall_s"]), np.asarray(timed["kernel_ms"])
     barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.repeats):
-        env.rollout(args.policy, args.steps)     # EXACTLY K steps per launch
-        metrics = gather()                       # the only collective; side stream
-        kms = env.last_kernel_ms()               # HIP events on the launch stream; also synchronises
-        best_ms = kms if best_ms is None else min(best_ms, kms)
-    wall = (time.perf_counter() - t0) / args.repeats     # this rank is done (the event wait above synchronised); the max over ranks follows
-    barrier()
-    kernel_ms = kms if args.repeats == 1 else best_ms
     if rdzv is not None:
-        wall, kernel_ms = [float(x) for x in rdzv.max([wall, kernel_ms])]     # max over ranks
-    kernel_s = kernel_ms / 1e3
+        both = rdzv.max(np.concatenate([walls, kmss]))               # per launch: the max over ranks
+        walls, kmss = both[:repeats], both[repeats:]
+    wall = float(np.median(walls))                                   # the median launch (max over ranks taken first)
+    kernel_s = float(np.mean(kmss)) / 1e3                            # average launch duration of the kernel over the timed region (HIP events)
 
     if rank == 0:
         total_envs = args.envs_per_gpu * world
@@ -276,11 +287,11 @@ def main():
                 "traffic": None, "kernel": env.kernel_name(), "kernel_ms_per_launch": kernel_s * 1e3,
                 "algorithmic_bytes_per_launch": bytes_per_launch, "frac_of_measured_copy_6290": achieved / HBM_MEASURED_COPY_GBS,
                 "rays_per_s": args.envs_per_gpu * args.cars * args.rays * args.steps / kernel_s,
-                # `bound` names the roofline SURVEY.md 8d prescribes for this path (its algorithmic bytes against HBM); what actually
-                # limits the kernel is vector-instruction issue, far above the HBM ridge -- see `valu`
-                "limiter": "vector-instruction issue: the SIMDs' vector pipes are busy more than 90 % of the time (valu.busy_frac) with "
-                           "instructions that cost 2-4 cycles each; the measured fabric traffic is a sixth of the HBM peak"}
-        tr = committed_counters("traffic", args.envs_per_gpu, args.rays, args.cars, args.policy, args.track)
+                # `frac` (= frac_hbm) is the figure SURVEY.md 8d prescribes for this path: its algorithmic bytes against the HBM peak.
+                # `bound` says what the committed counters show to be the limit (set below); without counters it stays "hbm".
+                "frac_hbm": achieved / HBM_PEAK_GBS}
+        rangefinder = args.lidar == "rangefinder"         # the committed counters were taken in that mode
+        tr = committed_counters("traffic", args.envs_per_gpu, args.rays, args.cars, args.policy, args.track) if rangefinder else None
         if tr is not None:
             # HBM bytes per launch = the committed PMC figure per env-step (FETCH_SIZE x2 + WRITE_SIZE, separate passes) scaled to this launch
             roof["traffic"] = tr["traffic_bytes_per_env_step"] * args.envs_per_gpu * args.steps
@@ -289,7 +300,7 @@ def main():
             roof["traffic_source"] = {"file": tr["file"], "measured_in_this_run": False,
                                       "kernel_source_sha": tr.get("kernel_source_sha"), "stale": tr["stale"],
                                       "bytes_per_env_step": tr["traffic_bytes_per_env_step"]}
-        sq = committed_counters("sq", args.envs_per_gpu, args.rays, args.cars, args.policy, args.track)
+        sq = committed_counters("sq", args.envs_per_gpu, args.rays, args.cars, args.policy, args.track) if rangefinder else None
         if sq is not None:
             c, steps_c = sq["counters"], sq["steps"]
             valu_per_car_step = c["SQ_INSTS_VALU"] / (sq["n_envs"] * sq.get("cars", 1) * steps_c)
@@ -300,10 +311,24 @@ def main():
                             "shader_clock_ghz": cycles / (sq["kernel_ms"] * 1e6) if sq.get("kernel_ms") else None,
                             "source": {"file": sq["file"], "measured_in_this_run": False,
                                        "kernel_source_sha": sq.get("kernel_source_sha"), "stale": sq["stale"]}}
+        if "valu" in roof:
+            # the vector pipes against their own peak, beside the HBM figure: one wave64 instruction per 2 cycles and SIMD is the issue peak
+            v = roof["valu"]
+            roof["frac_valu_issue"], roof["frac_valu_busy"] = v["issue_frac"], v["busy_frac"]
+            fabric = roof.get("measured_traffic_gbs", achieved) / HBM_PEAK_GBS
+            if v["busy_frac"] >= 0.6 and v["busy_frac"] > 2.0 * fabric:
+                roof["bound"] = "valu-issue"
+            roof["limiter"] = (f"vector-instruction issue: the SIMDs' vector pipes are busy {100 * v['busy_frac']:.0f} % of the time "
+                               f"(frac_valu_busy) at {100 * v['issue_frac']:.0f} % of the 2-cycle issue peak (frac_valu_issue: the instructions cost 2-4 "
+                               f"cycles each); the fabric traffic is {100 * fabric:.0f} % of the HBM peak"
+                               if roof["bound"] == "valu-issue" else
+                               f"HBM / fabric traffic at {100 * fabric:.0f} % of the peak; vector pipes busy {100 * v['busy_frac']:.0f} %")
         out = {
             "metric": "env-steps/sec (4096 envs, 1080-ray LiDAR) at 1/2/4/8 MI355X; HBM roofline %",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": wall * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": wall * 1e3 / args.steps, "repeats": repeats,
+            "ms_per_step_best": float(walls.min()) * 1e3 / args.steps, "ms_per_step_worst": float(walls.max()) * 1e3 / args.steps,
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32 rays + f64 state", "data": "synthetic",
             "config": {"workload": f"{args.envs_per_gpu} envs/GPU x {args.cars} car(s), {args.track} track blob, "
                                    f"{args.rays}-ray LiDAR, {args.policy} driver on device ({baseline_config(args, world)})",
@@ -316,6 +341,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(track, args.rays, args.policy, args.cars, seed)
         print(json.dumps(out), flush=True)
+    exchange.close()
+    if rdzv_x is not None:
+        rdzv_x.close()
     if rdzv is not None:
         rdzv.barrier()
         rdzv.close()

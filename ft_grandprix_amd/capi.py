@@ -15,7 +15,7 @@ import numpy as np
 
 from .track import Track
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 PATH_POINTS = 100
 MAX_LAP_TIMES = 32
 SNAPSHOT_DOUBLES = 10
@@ -24,6 +24,8 @@ PROGRESS_INTS = 10
 METRIC_DOUBLES = 8
 
 POLICY_HOST, POLICY_LOBOTOMY, POLICY_NIDC, POLICY_FAST, POLICY_RANDOM = 0, 1, 2, 3, 4
+LIDAR_RANGEFINDER, LIDAR_FAKELIDAR = 0, 1
+LIDAR_BY_NAME = {"rangefinder": LIDAR_RANGEFINDER, "fakelidar": LIDAR_FAKELIDAR}
 POLICY_BY_NAME = {"host": POLICY_HOST, "lobotomy": POLICY_LOBOTOMY, "nidc": POLICY_NIDC,
                   "fast": POLICY_FAST, "random": POLICY_RANDOM}
 
@@ -62,6 +64,7 @@ class FtgpConfig(C.Structure):
                 ("n_rays", C.c_int32), ("lap_target", C.c_int32), ("device_id", C.c_int32),
                 ("spawn_mode", C.c_int32), ("env_base", C.c_int32), ("seed", C.c_uint64),
                 ("dt", C.c_double), ("bubble_wrap", C.c_int32), ("naive_flatten", C.c_int32),
+                ("lidar_mode", C.c_int32), ("reserved2", C.c_int32), ("map_size", C.c_double), ("fan_dirs", C.c_void_p),
                 ("track", FtgpTrack), ("vehicle", FtgpVehicle)]
 
 
@@ -70,6 +73,7 @@ API_SYMBOLS = (
     "default_vehicle", "tricycle_vehicle", "last_error", "device_count", "create", "destroy", "reset", "set_ctrl", "step",
     "rollout", "get_lidar", "get_snapshot", "get_pose", "get_progress", "get_winners", "get_lap_times", "get_ctrl",
     "get_steps", "set_pose", "policy_eval", "eval_progress", "metrics_local", "comm_unique_id", "comm_init", "metrics_allgather",
+    "metrics_allgather_begin", "metrics_allgather_end", "get_distance_field",
     "last_kernel_ms", "kernel_name", "fakelidar", "selftest",
 )
 
@@ -130,6 +134,9 @@ class CLib:
             "comm_unique_id": (i32, [dp]),
             "comm_init": (i32, [vp, dp, i32, i32]),
             "metrics_allgather": (i32, [vp, dp]),
+            "metrics_allgather_begin": (i32, [vp]),
+            "metrics_allgather_end": (i32, [vp, dp]),
+            "get_distance_field": (i32, [vp, dp]),
             "fakelidar": (i32, [i32, dp, i32, i32, i32, dp, i32, dp, dp, C.c_double, dp, dp]),
             "last_kernel_ms": (i32, [vp, C.POINTER(C.c_float)]),
             "kernel_name": (C.c_char_p, [vp]),
@@ -183,7 +190,8 @@ class Env:
     def __init__(self, lib: CLib, track: Track, n_envs: int = 1, cars_per_env: int = 1, n_rays: int = 90,
                  lap_target: int = 10, dt: float = 0.004, spawn_mode: int = 0, seed: int = 1234,
                  device_id: int = 0, vehicle: Optional[FtgpVehicle] = None, env_base: int = 0,
-                 bubble_wrap: bool = False, naive_flatten: bool = False):
+                 bubble_wrap: bool = False, naive_flatten: bool = False, lidar_mode="rangefinder", map_size: float = 0.0,
+                 fan_dirs: Optional[np.ndarray] = None):
         self.lib, self.track = lib, track
         self.n_envs, self.cars_per_env, self.n_rays = int(n_envs), int(cars_per_env), int(n_rays)
         self.n_cars = self.n_envs * self.cars_per_env
@@ -194,6 +202,10 @@ class Env:
         cfg.lap_target, cfg.device_id, cfg.spawn_mode, cfg.seed, cfg.dt = lap_target, device_id, spawn_mode, seed, dt
         cfg.env_base = env_base
         cfg.bubble_wrap, cfg.naive_flatten = int(bool(bubble_wrap)), int(bool(naive_flatten))
+        cfg.lidar_mode = LIDAR_BY_NAME[lidar_mode] if isinstance(lidar_mode, str) else int(lidar_mode)
+        cfg.map_size = float(map_size)
+        self._fan = None if fan_dirs is None else np.ascontiguousarray(fan_dirs, dtype=np.float64).reshape(self.n_rays, 2)
+        cfg.fan_dirs = None if self._fan is None else self._fan.ctypes.data
         self.env_base = int(env_base)
         self._bits = np.ascontiguousarray(track.bits, dtype=np.uint32)
         self._path = np.ascontiguousarray(track.path, dtype=np.float64)
@@ -289,6 +301,8 @@ class Env:
         return out.reshape(self.n_envs, self.cars_per_env)
 
     def lap_times(self):
+        """(counts, ring): counts[i] = len(VehicleState.times) of car i (the true count), ring[i] = the ring of its newest
+        MAX_LAP_TIMES lap times, lap time k in slot k % MAX_LAP_TIMES (see ``lap_time_list``)."""
         counts = np.empty(self.n_cars, dtype=np.int32)
         times = np.empty((self.n_cars, MAX_LAP_TIMES), dtype=np.float64)
         self._call("get_lap_times", _ptr(counts), _ptr(times))
@@ -321,6 +335,22 @@ class Env:
         self._call("metrics_allgather", _ptr(out))
         return out
 
+    def metrics_allgather_begin(self):
+        """Enqueue the exchange of the latest launch's record on the side stream and return at once."""
+        self._call("metrics_allgather_begin")
+
+    def metrics_allgather_end(self) -> np.ndarray:
+        """Wait for the exchange begun last (not for any later launch) and return the [world, 8] records."""
+        out = np.empty((getattr(self, "world_size", 1), METRIC_DOUBLES), dtype=np.float64)
+        self._call("metrics_allgather_end", _ptr(out))
+        return out
+
+    def distance_field(self) -> np.ndarray:
+        """FAKELIDAR mode: the Euclidean distance transform built at create, float64 [H, W] in pixels (self.dt of custom.py:1152-1153)."""
+        out = np.empty((self.track.height, self.track.width), dtype=np.float64)
+        self._call("get_distance_field", _ptr(out))
+        return out
+
     def last_kernel_ms(self) -> float:
         ms = C.c_float()
         self._call("last_kernel_ms", C.byref(ms))
@@ -329,6 +359,14 @@ class Env:
     def kernel_name(self) -> str:
         s = self.lib.fn("kernel_name")(self.h)
         return s.decode() if s else ""
+
+
+def lap_time_list(count: int, ring: np.ndarray) -> list:
+    """The tail of VehicleState.times (custom.py:124) that the ring still holds, oldest first: all ``count`` lap times while
+    count <= MAX_LAP_TIMES, the newest MAX_LAP_TIMES after that."""
+    count = int(count)
+    first = max(0, count - MAX_LAP_TIMES)
+    return [float(ring[k % MAX_LAP_TIMES]) for k in range(first, count)]
 
 
 def fakelidar(lib: CLib, dt: np.ndarray, origins: np.ndarray, cosines: np.ndarray, sines: np.ndarray, eps: float = 2.0,

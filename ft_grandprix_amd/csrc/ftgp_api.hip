@@ -68,7 +68,7 @@ struct FtgpEnv {
     FtgpConfig cfg{};
     int device = 0;
     hipStream_t stream = nullptr, side = nullptr;
-    hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_metrics = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_metrics = nullptr, ev_gather = nullptr;
     bool timed = false;
     // device buffers
     uint16_t* d_field = nullptr; uint32_t* d_bits = nullptr; uint32_t* d_nearbits = nullptr;
@@ -76,10 +76,16 @@ struct FtgpEnv {
     CarState* d_cars = nullptr; float* d_ranges = nullptr; int64_t* d_steps = nullptr;
     uint8_t* d_env_mask = nullptr; uint8_t* d_car_mask = nullptr; double* d_ctrl = nullptr; double* d_pose = nullptr;
     double* d_metrics = nullptr; double* d_gather = nullptr; double* d_wg_metrics = nullptr; unsigned int* d_wg_ticket = nullptr;
-    bool launch_metrics_valid = false;   // the record the last step launch left in d_metrics / h_metrics still describes the state (no reset / set_pose / ... since)
-    double* h_metrics = nullptr;      // pinned landing buffer of the metrics record(s): the copy back is one small DMA, not a staged one
-    int h_metrics_ranks = 0;
-    double* h_metrics_dev = nullptr;  // the same buffer as the device sees it: a single-rank record is written straight into it
+    double* d_edt = nullptr; double* d_fan = nullptr;      // FTGP_LIDAR_FAKELIDAR: distance transform, binary64 fan
+    // This rank's metrics record lives in two slots (device memory for RCCL, pinned host memory for the caller) that successive
+    // launches alternate between, so that the exchange of launch k's record can run beside launch k + 1.
+    int cur_slot = 0;                    // slot of the most recent step launch (or of the record ftgp_metrics_kernel refreshed)
+    bool launch_metrics_valid = false;   // slot cur_slot of d_metrics / h_metrics still describes the state (no reset / set_pose / ... since)
+    double* h_metrics = nullptr;      // pinned [2][FTGP_METRIC_DOUBLES]: THIS rank's records only (the gathered ones land in h_gather)
+    double* h_metrics_dev = nullptr;  // the same buffer as the device sees it: the step kernel's epilogue writes straight into it
+    double* h_gather = nullptr;       // pinned [world][FTGP_METRIC_DOUBLES]: landing buffer of the all-gather
+    bool gather_open = false;         // ftgp_metrics_allgather_begin without its _end
+    int gather_slot = 0;              // the slot that exchange reads
     int32_t* d_prog = nullptr; double* d_core = nullptr;
     std::vector<int32_t> h_prog; std::vector<double> h_core;
     bool rows_valid = false;          // h_prog / h_core mirror the device state (cleared by every call that changes it)
@@ -213,13 +219,20 @@ int launch_steps(FtgpEnv* e, int policy, int n_steps)
     HIP_TRY(hipSetDevice(e->device));
     const int cpb = e->P.cars_per_block;
     const int blocks = (e->P.n_cars + cpb - 1) / cpb;
+    const int slot = e->cur_slot ^ 1;
+    // an exchange that is still reading this launch's slot (begin without end, two launches ago) goes first -- on the device
+    if (n_steps > 0 && e->gather_open && e->gather_slot == slot) HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_gather, 0));
     HIP_TRY(hipEventRecord(e->ev_start, e->stream));
     if (n_steps > 0) {
         const dim3 grid(blocks), block(e->P.waves_per_block * FTGP_WAVE);
         const size_t lds = (size_t)e->P.lds_bytes;
-        if (e->multi) hipLaunchKernelGGL((ftgp_step_kernel<true>), grid, block, lds, e->stream, e->d_params, policy, n_steps);
-        else          hipLaunchKernelGGL((ftgp_step_kernel<false>), grid, block, lds, e->stream, e->d_params, policy, n_steps);
+        const bool fake = e->P.lidar_mode == FTGP_LIDAR_FAKELIDAR;
+        if (e->multi) { if (fake) hipLaunchKernelGGL((ftgp_step_kernel<true, true>), grid, block, lds, e->stream, e->d_params, policy, n_steps, slot);
+                        else      hipLaunchKernelGGL((ftgp_step_kernel<true, false>), grid, block, lds, e->stream, e->d_params, policy, n_steps, slot); }
+        else          { if (fake) hipLaunchKernelGGL((ftgp_step_kernel<false, true>), grid, block, lds, e->stream, e->d_params, policy, n_steps, slot);
+                        else      hipLaunchKernelGGL((ftgp_step_kernel<false, false>), grid, block, lds, e->stream, e->d_params, policy, n_steps, slot); }
         HIP_TRY(hipGetLastError());
+        e->cur_slot = slot;
         e->launch_metrics_valid = e->d_wg_metrics != nullptr;
     }
     HIP_TRY(hipEventRecord(e->ev_stop, e->stream));
@@ -324,9 +337,12 @@ int ftgp_destroy(FtgpEnv* e)
     if (e->side) (void)hipStreamSynchronize(e->side);
     if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
     void* bufs[] = { e->d_field, e->d_bits, e->d_nearbits, e->d_cover, e->d_params, e->d_veh, e->d_path, e->d_spawn, e->d_ray, e->d_cars, e->d_ranges,
-                     e->d_steps, e->d_env_mask, e->d_car_mask, e->d_ctrl, e->d_pose, e->d_metrics, e->d_gather, e->d_prog, e->d_core, e->d_wg_metrics, e->d_wg_ticket };
+                     e->d_steps, e->d_env_mask, e->d_car_mask, e->d_ctrl, e->d_pose, e->d_metrics, e->d_gather, e->d_prog, e->d_core, e->d_wg_metrics, e->d_wg_ticket,
+                     e->d_edt, e->d_fan };
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (e->h_metrics) (void)hipHostFree(e->h_metrics);
+    if (e->h_gather) (void)hipHostFree(e->h_gather);
+    if (e->ev_gather) (void)hipEventDestroy(e->ev_gather);
     if (e->ev_start) (void)hipEventDestroy(e->ev_start);
     if (e->ev_stop) (void)hipEventDestroy(e->ev_stop);
     if (e->ev_metrics) (void)hipEventDestroy(e->ev_metrics);
@@ -353,6 +369,7 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
     if ((uint64_t)ftgp_plane256(t.width, t.height) * 256u * FTGP_SECTORS > 0xFFFFFFFFull)
         return fail(FTGP_ERR_ARG, "track image too large: the sector box field (128 bytes per pixel) must stay below 4 GiB (about 33 million pixels)%s");
     if (cfg->env_base < 0) return fail(FTGP_ERR_ARG, "env_base < 0%s");
+    if (cfg->lidar_mode != FTGP_LIDAR_RANGEFINDER && cfg->lidar_mode != FTGP_LIDAR_FAKELIDAR) return fail(FTGP_ERR_ARG, "unknown lidar_mode%s");
     if (!(cfg->dt > 0.0) || !(t.px_size_x > 0.0) || !(t.px_size_y > 0.0)) return fail(FTGP_ERR_ARG, "bad dt / pixel size%s");
     const FtgpVehicle& v = cfg->vehicle;
     if (!(v.contact_radius > 0.0) || !(v.mass > 0.0) || !(v.izz > 0.0) || (v.kind != FTGP_VEHICLE_MUSHR && v.kind != FTGP_VEHICLE_TRICYCLE))
@@ -381,6 +398,7 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
     CREATE_TRY(hipEventCreate(&e->ev_start));
     CREATE_TRY(hipEventCreate(&e->ev_stop));
     CREATE_TRY(hipEventCreateWithFlags(&e->ev_metrics, hipEventDisableTiming));
+    CREATE_TRY(hipEventCreateWithFlags(&e->ev_gather, hipEventDisableTiming));
 
     DeviceParams& P = e->P;
     P.n_envs = cfg->n_envs; P.cars_per_env = cfg->cars_per_env; P.n_cars = cfg->n_envs * cfg->cars_per_env;
@@ -389,6 +407,8 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
     P.seed = cfg->seed; P.dt = cfg->dt;
     P.rpp = (2 * M_PI) / (double)cfg->n_rays;
     P.bubble_wrap = cfg->bubble_wrap ? 1 : 0;        // cfg->naive_flatten: accepted, no effect on a planar model (custom.py:1338-1339)
+    P.lidar_mode = cfg->lidar_mode;
+    P.map_size = cfg->map_size > 0.0 ? cfg->map_size : 40.0;                     // 20 * scale, custom.py:1155,1382
     P.width = t.width; P.height = t.height; P.words_per_row = t.words_per_row; P.fstride = t.width + 2;
     P.plane256 = ftgp_plane256(t.width, t.height);
     for (uint32_t q = 0; q < FTGP_SECTORS; ++q) ftgp_sector_entry(P.sector_tab[q], q, t.width + 2, P.plane256);
@@ -455,17 +475,22 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
                 return FTGP_ERR_ARG;
             }
     }
-    CREATE_TRY(hipFuncSetAttribute((const void*)ftgp_step_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    CREATE_TRY(hipFuncSetAttribute((const void*)ftgp_step_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CREATE_TRY(hipFuncSetAttribute((const void*)ftgp_step_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CREATE_TRY(hipFuncSetAttribute((const void*)ftgp_step_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CREATE_TRY(hipFuncSetAttribute((const void*)ftgp_step_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CREATE_TRY(hipFuncSetAttribute((const void*)ftgp_step_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 
     // host-side tables
     HostTables tab;
     build_tables(t, P.contact_reach, tab);
     std::vector<float> ray(2 * (size_t)cfg->n_rays + 4, 0.0f);
+    std::vector<double> fan(2 * (size_t)cfg->n_rays, 0.0);
     for (int j = 0; j < cfg->n_rays; ++j) {
         // mushr.em.xml:112-117: phi_j = radians(360/R*j - 90); the ray (+z of the site) is (sin phi, -cos phi, 0)
         const double phi = ((360.0 / (double)cfg->n_rays) * (double)j - 90.0) * (M_PI / 180.0);
-        ray[2 * (size_t)j] = (float)sin(phi); ray[2 * (size_t)j + 1] = (float)(-cos(phi));
+        fan[2 * (size_t)j] = cfg->fan_dirs ? cfg->fan_dirs[2 * (size_t)j] : sin(phi);
+        fan[2 * (size_t)j + 1] = cfg->fan_dirs ? cfg->fan_dirs[2 * (size_t)j + 1] : -cos(phi);
+        ray[2 * (size_t)j] = (float)fan[2 * (size_t)j]; ray[2 * (size_t)j + 1] = (float)fan[2 * (size_t)j + 1];
     }
     std::vector<double> spawn(4 * FTGP_PATH_POINTS);
     for (int p = 0; p < FTGP_PATH_POINTS; ++p) {
@@ -476,7 +501,23 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
         spawn[4 * p + 2] = cos(ang / 2); spawn[4 * p + 3] = sin(ang / 2);
     }
 
-    {   // sector box field: upload the run lengths, search the boxes on the device
+    if (cfg->lidar_mode == FTGP_LIDAR_FAKELIDAR) {
+        // The distance transform of custom.py:1149-1153 / raycast.py:24-27 (scipy.ndimage.distance_transform_edt of the non-wall
+        // mask) without scipy, exact: the squared distance is the minimum over the columns x' of (x - x')^2 + g(x', y)^2 with g the
+        // vertical distance to the nearest wall of column x' -- the run lengths above -- in integers; one correctly rounded sqrt.
+        const size_t plane = (size_t)t.width * t.height;
+        uint16_t* d_runy = nullptr;
+        CREATE_TRY(hipMalloc(&d_runy, 2 * plane * sizeof(uint16_t)));
+        CREATE_TRY(hipMalloc(&e->d_edt, plane * sizeof(double)));
+        CREATE_TRY(hipMalloc(&e->d_fan, fan.size() * sizeof(double)));
+        CREATE_TRY(hipMemcpy(d_runy, tab.runy.data(), 2 * plane * sizeof(uint16_t), hipMemcpyHostToDevice));
+        CREATE_TRY(hipMemcpy(e->d_fan, fan.data(), fan.size() * sizeof(double), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(ftgp_edt_kernel, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, e->stream, d_runy, t.width, t.height, e->d_edt);
+        CREATE_TRY(hipGetLastError());
+        CREATE_TRY(hipStreamSynchronize(e->stream));
+        (void)hipFree(d_runy);
+        P.edt = e->d_edt; P.fan_dirs = e->d_fan;
+    } else {   // sector box field: upload the run lengths, search the boxes on the device
         const size_t plane = (size_t)t.width * t.height;
         const size_t cells = (size_t)P.plane256 * 128 * FTGP_SECTORS;
         uint16_t* d_runx = nullptr; uint16_t* d_runy = nullptr;
@@ -530,8 +571,8 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
     CREATE_TRY(hipMalloc(&e->d_car_mask, n_cars));
     CREATE_TRY(hipMalloc(&e->d_ctrl, sizeof(double) * 2 * n_cars));
     CREATE_TRY(hipMalloc(&e->d_pose, sizeof(double) * FTGP_POSE_DOUBLES * n_cars));
-    CREATE_TRY(hipMalloc(&e->d_metrics, sizeof(double) * FTGP_METRIC_DOUBLES));
-    CREATE_TRY(hipHostMalloc(&e->h_metrics, sizeof(double) * FTGP_METRIC_DOUBLES, hipHostMallocMapped)); e->h_metrics_ranks = 1;
+    CREATE_TRY(hipMalloc(&e->d_metrics, sizeof(double) * FTGP_METRIC_DOUBLES * 2));
+    CREATE_TRY(hipHostMalloc(&e->h_metrics, sizeof(double) * FTGP_METRIC_DOUBLES * 2, hipHostMallocMapped));
     CREATE_TRY(hipHostGetDevicePointer((void**)&e->h_metrics_dev, e->h_metrics, 0));
     if (!getenv("FTGP_NO_FUSED_METRICS")) {          // (diagnostic switch: tests compare the fused record with ftgp_metrics_kernel's)
         const size_t blocks = (n_cars + (size_t)P.cars_per_block - 1) / (size_t)P.cars_per_block;
@@ -768,18 +809,16 @@ int ftgp_get_steps(FtgpEnv* e, int64_t* out)
     return 0;
 }
 
-// the record of this GPU, reduced on the compute stream and written by the kernel straight into pinned host memory
+// the record of this GPU: the step kernel's last workgroup has written it into pinned memory (slot cur_slot), or ftgp_metrics_kernel does now
 static int metrics_to_host(FtgpEnv* e, double* out)
 {
-    if (e->launch_metrics_valid) {       // the step kernel's last workgroup has written the record of this very state into pinned memory
-        HIP_TRY(hipStreamSynchronize(e->stream));
-        memcpy(out, e->h_metrics, sizeof(double) * FTGP_METRIC_DOUBLES);
-        return 0;
+    double* slot_host = e->h_metrics + (size_t)e->cur_slot * FTGP_METRIC_DOUBLES;
+    if (!e->launch_metrics_valid) {
+        hipLaunchKernelGGL(ftgp_metrics_kernel, dim3(1), dim3(FTGP_METRIC_THREADS), 0, e->stream, e->P, e->h_metrics_dev + (size_t)e->cur_slot * FTGP_METRIC_DOUBLES);
+        HIP_TRY(hipGetLastError());
     }
-    hipLaunchKernelGGL(ftgp_metrics_kernel, dim3(1), dim3(FTGP_METRIC_THREADS), 0, e->stream, e->P, e->h_metrics_dev);
-    HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(e->stream));
-    memcpy(out, e->h_metrics, sizeof(double) * FTGP_METRIC_DOUBLES);
+    memcpy(out, slot_host, sizeof(double) * FTGP_METRIC_DOUBLES);
     return 0;
 }
 
@@ -804,46 +843,71 @@ int ftgp_comm_unique_id(uint8_t id_out[128])
 int ftgp_comm_init(FtgpEnv* e, const uint8_t id[128], int rank, int world_size)
 {
     if (!e || !id || world_size < 1 || rank < 0 || rank >= world_size) return fail(FTGP_ERR_ARG, "bad comm arguments%s");
+    if (e->comm) return fail(FTGP_ERR_STATE, "the handle already has a communicator%s");
     if (int rc = load_rccl()) return rc;
     HIP_TRY(hipSetDevice(e->device));
     Id128 uid; memcpy(uid.internal, id, 128);
     int r = g_rccl.CommInitRank(&e->comm, world_size, uid, rank);
-    if (r != 0) return fail(FTGP_ERR_COMM, "ncclCommInitRank: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    if (r != 0) { e->comm = nullptr; return fail(FTGP_ERR_COMM, "ncclCommInitRank: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"); }
     e->rank = rank; e->world = world_size;
+    // the gathered records get buffers of their own: this rank's record slots (h_metrics, written by the step kernel) stay untouched
     HIP_TRY(hipMalloc(&e->d_gather, sizeof(double) * FTGP_METRIC_DOUBLES * (size_t)world_size));
-    if (world_size > e->h_metrics_ranks) {
-        if (e->h_metrics) (void)hipHostFree(e->h_metrics);
-        e->h_metrics = nullptr; e->h_metrics_ranks = 0;
-        HIP_TRY(hipHostMalloc(&e->h_metrics, sizeof(double) * FTGP_METRIC_DOUBLES * (size_t)world_size, hipHostMallocMapped));
-        HIP_TRY(hipHostGetDevicePointer((void**)&e->h_metrics_dev, e->h_metrics, 0));
-        e->h_metrics_ranks = world_size;
-        if (e->P.metrics_host) {         // the step kernel's epilogue writes this rank's record there: tell it about the new buffer
-            e->P.metrics_host = e->h_metrics_dev;
-            HIP_TRY(hipStreamSynchronize(e->stream));
-            HIP_TRY(hipMemcpy(e->d_params, &e->P, sizeof(DeviceParams), hipMemcpyHostToDevice));
-            e->launch_metrics_valid = false;
-        }
+    HIP_TRY(hipHostMalloc(&e->h_gather, sizeof(double) * FTGP_METRIC_DOUBLES * (size_t)world_size, hipHostMallocDefault));
+    return 0;
+}
+
+int ftgp_metrics_allgather_begin(FtgpEnv* e)
+{
+    if (!e) return fail(FTGP_ERR_ARG, "null handle%s");
+    if (e->gather_open) return fail(FTGP_ERR_STATE, "ftgp_metrics_allgather_begin: the previous exchange has not been ended%s");
+    HIP_TRY(hipSetDevice(e->device));
+    const int slot = e->cur_slot;
+    const size_t so = (size_t)slot * FTGP_METRIC_DOUBLES;
+    const bool rccl = e->comm != nullptr;            // a one-rank communicator goes through RCCL too (that is how one GPU tests the path)
+    if (!e->launch_metrics_valid) {      // otherwise the slot already holds this state's record (step kernel epilogue), on the device and in pinned memory
+        hipLaunchKernelGGL(ftgp_metrics_kernel, dim3(1), dim3(FTGP_METRIC_THREADS), 0, e->stream, e->P, rccl ? e->d_metrics + so : e->h_metrics_dev + so);
+        HIP_TRY(hipGetLastError());
     }
+    if (!rccl) {                         // one rank: the "exchange" is the record's arrival in pinned memory
+        HIP_TRY(hipEventRecord(e->ev_gather, e->stream));
+    } else {
+        // the record is produced on the compute stream; everything else happens on the side stream, beside the next launch
+        HIP_TRY(hipEventRecord(e->ev_metrics, e->stream));
+        HIP_TRY(hipStreamWaitEvent(e->side, e->ev_metrics, 0));
+        int r = g_rccl.AllGather(e->d_metrics + so, e->d_gather, FTGP_METRIC_DOUBLES, kNcclFloat64, e->comm, e->side);
+        if (r != 0) return fail(FTGP_ERR_COMM, "ncclAllGather: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+        HIP_TRY(hipMemcpyAsync(e->h_gather, e->d_gather, sizeof(double) * FTGP_METRIC_DOUBLES * (size_t)e->world, hipMemcpyDeviceToHost, e->side));
+        HIP_TRY(hipEventRecord(e->ev_gather, e->side));
+    }
+    e->gather_open = true; e->gather_slot = slot;
+    return 0;
+}
+
+int ftgp_metrics_allgather_end(FtgpEnv* e, double* out)
+{
+    if (!e || !out) return fail(FTGP_ERR_ARG, "null argument%s");
+    if (!e->gather_open) return fail(FTGP_ERR_STATE, "ftgp_metrics_allgather_end without _begin%s");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipEventSynchronize(e->ev_gather));          // this exchange only: a later launch on the compute stream is not waited for
+    e->gather_open = false;
+    if (e->comm) memcpy(out, e->h_gather, sizeof(double) * FTGP_METRIC_DOUBLES * (size_t)e->world);
+    else memcpy(out, e->h_metrics + (size_t)e->gather_slot * FTGP_METRIC_DOUBLES, sizeof(double) * FTGP_METRIC_DOUBLES);
     return 0;
 }
 
 int ftgp_metrics_allgather(FtgpEnv* e, double* out)
 {
     if (!e || !out) return fail(FTGP_ERR_ARG, "null argument%s");
+    if (int rc = ftgp_metrics_allgather_begin(e)) return rc;
+    return ftgp_metrics_allgather_end(e, out);
+}
+
+int ftgp_get_distance_field(FtgpEnv* e, double* out)
+{
+    if (!e || !out) return fail(FTGP_ERR_ARG, "null argument%s");
+    if (!e->d_edt) return fail(FTGP_ERR_STATE, "no distance field: the handle was not created with lidar_mode = FTGP_LIDAR_FAKELIDAR%s");
     HIP_TRY(hipSetDevice(e->device));
-    // reduce on the compute stream (it reads the state the step kernel wrote), gather on the side stream
-    if (!e->comm || e->world == 1) return metrics_to_host(e, out);
-    if (!e->launch_metrics_valid) {      // otherwise d_metrics already holds this state's record (step kernel epilogue)
-        hipLaunchKernelGGL(ftgp_metrics_kernel, dim3(1), dim3(FTGP_METRIC_THREADS), 0, e->stream, e->P, e->d_metrics);
-        HIP_TRY(hipGetLastError());
-    }
-    HIP_TRY(hipEventRecord(e->ev_metrics, e->stream));
-    HIP_TRY(hipStreamWaitEvent(e->side, e->ev_metrics, 0));
-    int r = g_rccl.AllGather(e->d_metrics, e->d_gather, FTGP_METRIC_DOUBLES, kNcclFloat64, e->comm, e->side);
-    if (r != 0) return fail(FTGP_ERR_COMM, "ncclAllGather: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
-    HIP_TRY(hipMemcpyAsync(e->h_metrics, e->d_gather, sizeof(double) * FTGP_METRIC_DOUBLES * (size_t)e->world, hipMemcpyDeviceToHost, e->side));
-    HIP_TRY(hipStreamSynchronize(e->side));
-    memcpy(out, e->h_metrics, sizeof(double) * FTGP_METRIC_DOUBLES * (size_t)e->world);
+    HIP_TRY(hipMemcpy(out, e->d_edt, sizeof(double) * (size_t)e->P.width * e->P.height, hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -930,7 +994,8 @@ int ftgp_selftest(int device_id, int64_t* mismatches)
 const char* ftgp_kernel_name(FtgpEnv* e)
 {
     if (!e) return "ftgp_step_kernel";
-    return e->multi ? "ftgp_step_kernel<true>" : "ftgp_step_kernel<false>";
+    if (e->P.lidar_mode == FTGP_LIDAR_FAKELIDAR) return e->multi ? "ftgp_step_kernel<true, true>" : "ftgp_step_kernel<false, true>";
+    return e->multi ? "ftgp_step_kernel<true, false>" : "ftgp_step_kernel<false, false>";
 }
 
 }  // extern "C"

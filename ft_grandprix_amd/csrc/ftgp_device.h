@@ -29,6 +29,7 @@ struct alignas(16) CarState : CarCore {
 };
 static_assert(sizeof(CarCore) == 192, "CarCore layout");
 static_assert(sizeof(CarState) == 192 + 8 * FTGP_MAX_LAP_TIMES, "CarState layout");
+static_assert((FTGP_MAX_LAP_TIMES & (FTGP_MAX_LAP_TIMES - 1)) == 0, "the lap-time ring is indexed with a mask");
 
 // LiDAR frame of one car, refreshed in LDS before every sweep: the sweep never reads the live state, so the dynamics
 // of the same step can run beside it.  The second half is what OTHER cars of the env need to see this car.
@@ -71,6 +72,11 @@ struct DeviceParams {
     int32_t bubble_wrap;          // custom.py:1041-1055: the four wheel softeners collide with the walls
     int32_t n_cu, pad_c;          // compute units of the device (sweep_priority)
     float edge_margin, pad_d;     // pixels: a LiDAR centre at least this far from every image edge has all its ray origins on the image (frame_write)
+    // FTGP_LIDAR_FAKELIDAR (raycast.py:5-21 inside the step loop): the distance transform, the binary64 fan and the world size of the map
+    const double* edt;            // [height][width] exact Euclidean distance to the nearest wall pixel (0 on walls), pixels; null in RANGEFINDER mode
+    const double* fan_dirs;       // [n_rays][2] body-frame fan directions, binary64
+    double map_size;              // 20 * scale = 40 (custom.py:1382)
+    int32_t lidar_mode, pad_e;
     const uint16_t* field;        // [FTGP_SECTORS][height + 2][width + 2] box entries (ftgp_march.h), HBM/L2
     const uint32_t* bits;         // [height][words_per_row] wall bitmap
     const uint32_t* nearbits;     // [height][words_per_row] wall bitmap dilated by contact_reach (early-out of the wall contact)
@@ -88,8 +94,8 @@ struct DeviceParams {
     // host memory for the caller); null: the step kernel leaves the metrics to ftgp_metrics_kernel
     double* wg_metrics;
     unsigned int* wg_ticket;
-    double* metrics_dev;
-    double* metrics_host;
+    double* metrics_dev;          // [2][FTGP_METRIC_DOUBLES]: the launch's slot (a kernel argument, alternating per launch) says which
+    double* metrics_host;         // [2][FTGP_METRIC_DOUBLES]
     alignas(16) int32_t sector_tab[FTGP_SECTORS][4];     // ftgp_sector_entry() of every sector (staged into LDS with the head of the block)
     FtgpVehicle veh;              // host-side copy (the step kernel reads the LDS image VehLds; from here on nothing is staged into LDS)
     double wheel_load[4];

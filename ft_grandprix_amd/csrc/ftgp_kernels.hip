@@ -411,6 +411,62 @@ __device__ __forceinline__ void lidar_pool(const DeviceParams& P, ScalarParams G
     }
 }
 
+// K2 in FTGP_LIDAR_FAKELIDAR mode: the reference's own 2-D LiDAR inside the step loop (option use_simulated_simulation_lidar,
+// custom.py:987,1381-1393).  Per ray, in binary64 and in the order of the Python statements:
+//   origin   i_x = (x / s) * W, i_y = -(y / s) * H of the car's position, s = 20 * scale (custom.py:1382-1384)
+//   ray j    image-frame direction (dxw, -dyw), (dxw, dyw) = R(yaw) * fan[j]: the rangefinders' order
+//   march    raycast.py:9-20: while dt[int(y), int(x)] > 2 and 0 <= x <= W and 0 <= y <= H: advance by dt
+//   range    (distance / W) * s (custom.py:1392-1393), stored as binary32
+// int() truncates toward zero and a negative index wraps like numpy's; an index past the end -- the reference's IndexError --
+// ends the ray with range -1.  Rays are dealt to lanes statically (this mode is for parity, not for throughput); the ranges go
+// where lidar_pool() puts them: the drivers' window in LDS, everything else straight to HBM.
+__device__ __forceinline__ void lidar_fake(ScalarParams G, const LidarFrame* frames, float* scan_rows, int ncars_here, int ci0, bool scan_lds, int wave, int nwaves)
+{
+    const int R = G->n_rays, total = ncars_here * R, W = G->width, H = G->height, stride = G->ranges_stride;
+    const int eighth = G->eighth, win_floats = G->win_floats;
+    const uint32_t magic = G->ray_magic;
+    const double s = G->map_size;
+    const double* __restrict__ dt = G->edt;
+    const double* __restrict__ fan = G->fan_dirs;
+    float* ranges = G->ranges + (size_t)ci0 * stride;
+    for (int g = wave * FTGP_WAVE + lane_here(); g < total; g += nwaves * FTGP_WAVE) {
+        const int c = (int)__umulhi((uint32_t)g, magic), j = g - c * R;
+        const LidarFrame* f = frames + c;
+        const double qw = f->qw, qz = f->qz;
+        const double ch = 1.0 - 2.0 * (qz * qz), sh = 2.0 * (qw * qz);
+        const double bx = fan[2 * j], by = fan[2 * j + 1];
+        const double dxw = ch * bx - sh * by, dyw = sh * bx + ch * by;
+        const double dx = dxw, dy = -dyw;
+        double x = (f->x / s) * (double)W, y = -(f->y / s) * (double)H;
+        double distance = 0.0;
+        bool bad = false;
+        long yi = (long)y, xi = (long)x;                          // int(): truncation toward zero
+        if (yi < 0) yi += H;
+        if (xi < 0) xi += W;                                      // numpy negative-index wrap
+        double nearest = 0.0;
+        if (yi < 0 || yi >= H || xi < 0 || xi >= W) bad = true; else nearest = dt[(size_t)yi * W + xi];
+        for (int guard = 0; guard < (1 << 20) && !bad && nearest > 2.0 && 0 <= x && x <= W && 0 <= y && y <= H; ++guard) {
+            distance += nearest;
+            x += dx * nearest;
+            y += dy * nearest;
+            yi = (long)y; xi = (long)x;
+            if (yi < 0) yi += H;
+            if (xi < 0) xi += W;
+            if (yi < 0 || yi >= H || xi < 0 || xi >= W) { bad = true; break; }
+            nearest = dt[(size_t)yi * W + xi];
+        }
+        const float r = bad ? -1.0f : (float)((distance / (double)W) * s);
+        const int jw = j - eighth;
+        const bool in_window = scan_lds && (unsigned)jw < (unsigned)(R - 2 * eighth);
+        if (!in_window) ranges[(size_t)c * stride + j] = r;
+        if (scan_lds) {
+            float* row = scan_rows + c * win_floats;
+            if (in_window) row[(eighth & 3) + jw] = r;
+            if (j == 0) row[win_floats - 1] = r;
+        }
+    }
+}
+
 // The scan window of a car (LDS row, see scan_window_first) to its row in HBM, by one wave: whole float4 groups -- 16 bytes per
 // lane, whole 128-byte lines per 8 lanes -- and single floats only at the two ragged ends of the window.
 template <class PP>
@@ -472,7 +528,7 @@ __device__ __forceinline__ void progress_update(const DeviceParams& P, Race& s, 
             if (s.n_times != 0) s.n_times -= 1;
         } else if (s.delta > 0) {                         // custom.py:1357-1366
             if (s.good_start) {
-                if (s.n_times < FTGP_MAX_LAP_TIMES) times[s.n_times] = lap_time;
+                times[s.n_times & (FTGP_MAX_LAP_TIMES - 1)] = lap_time;      // times.append(lap_time): a ring of the newest FTGP_MAX_LAP_TIMES
                 s.n_times += 1;
                 s.start = (int32_t)steps;
             }
@@ -1089,7 +1145,7 @@ __device__ __forceinline__ double wave_sum_f64(double v)
 
 // called by ALL threads of the workgroup, after the state records have gone back to HBM; `scratch`: one int of LDS
 __device__ __forceinline__ void launch_metrics(const DeviceParams& P, const CarCore* cars_lds, const int64_t* steps_lds, int ncars_here, int ci0,
-                                               unsigned char* scratch)
+                                               unsigned char* scratch, int slot)
 {
     int* last_flag = reinterpret_cast<int*>(scratch);
     const int lane = lane_id();
@@ -1101,7 +1157,7 @@ __device__ __forceinline__ void launch_metrics(const DeviceParams& P, const CarC
             const int lc = a->good_start ? a->completion : -(100 - a->completion);     // custom.py:132-143
             if (ci % P.cars_per_env == 0) v[0] = (double)steps_lds[lane];
             v[1] = a->laps; v[2] = a->laps * 100 + lc; v[3] = a->finished; v[4] = a->off_track;
-            const int n = a->n_times < FTGP_MAX_LAP_TIMES ? a->n_times : FTGP_MAX_LAP_TIMES;
+            const int n = a->n_times < FTGP_MAX_LAP_TIMES ? a->n_times : FTGP_MAX_LAP_TIMES;      // the ring's occupied slots
             const double* t = P.cars[ci].times;
             for (int k = 0; k < n; ++k) { v[5] = fmin(v[5], t[k]); v[6] = fmax(v[6], t[k]); }
         }
@@ -1141,7 +1197,7 @@ __device__ __forceinline__ void launch_metrics(const DeviceParams& P, const CarC
         for (int m = 32; m >= 1; m >>= 1) { v[6] = fmin(v[6], shfl_xor_f64(v[6], m)); v[7] = fmax(v[7], shfl_xor_f64(v[7], m)); }
         if (lane == 0) {
             #pragma unroll
-            for (int q = 0; q < FTGP_METRIC_DOUBLES; ++q) { P.metrics_dev[q] = v[q]; P.metrics_host[q] = v[q]; }
+            for (int q = 0; q < FTGP_METRIC_DOUBLES; ++q) { P.metrics_dev[slot * FTGP_METRIC_DOUBLES + q] = v[q]; P.metrics_host[slot * FTGP_METRIC_DOUBLES + q] = v[q]; }
             __hip_atomic_store(P.wg_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the next launch counts from zero again
         }
     }
@@ -1163,8 +1219,11 @@ __device__ __forceinline__ void stage16(void* dst, const void* src, int bytes)
 #ifndef FTGP_WAVES_PER_EU
 #define FTGP_WAVES_PER_EU 8       // two 16-wave workgroups per CU: at most 64 VGPRs per lane
 #endif
-template <bool MULTI>
-__global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(const DeviceParams* __restrict__ Pg, int policy, int n_steps)
+// MULTI: several cars per env (inter-vehicle rays and contacts).  FAKE: FTGP_LIDAR_FAKELIDAR -- the sweep is lidar_fake() (its own
+// instantiation, so that the rangefinder kernels' code generation does not move).  metrics_slot: which of the two record slots this
+// launch's metrics go to (ftgp_metrics_allgather_begin / _end).
+template <bool MULTI, bool FAKE>
+__global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(const DeviceParams* __restrict__ Pg, int policy, int n_steps, int metrics_slot)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const DeviceParams& P0 = *reinterpret_cast<const DeviceParams*>(lds + Pg->off_params);   // valid after staging + barrier
@@ -1282,7 +1341,8 @@ __global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(cons
             const LdsOffsets off = lds_offsets(G);
             const DeviceParams& P = *reinterpret_cast<const DeviceParams*>(lds + off.params);
             const Lds L = lds_view(off, lds);
-            lidar_pool<MULTI>(P, G, L, L.frame + par * cpb, L.pairs + par * cpb * FTGP_PAIR_STRIDE, L.scan + par * cpb * G->win_floats, L.pool + par, ncars_here, ci0, need_scan, second_half STAMP_PASS);
+            if (FAKE) lidar_fake(G, L.frame + par * cpb, L.scan + par * cpb * G->win_floats, ncars_here, ci0, need_scan, wave, nwaves);
+            else lidar_pool<MULTI>(P, G, L, L.frame + par * cpb, L.pairs + par * cpb * FTGP_PAIR_STRIDE, L.scan + par * cpb * G->win_floats, L.pool + par, ncars_here, ci0, need_scan, second_half STAMP_PASS);
         }
 #endif
         STAMP(t4);
@@ -1307,7 +1367,7 @@ __global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(cons
     }
     if (P.wg_metrics) {                  // the scan windows are dead now: their first bytes serve as the reduction scratch
         __syncthreads();
-        launch_metrics(P, L.cars, L.steps, ncars_here, ci0, lds + P.off_scan);
+        launch_metrics(P, L.cars, L.steps, ncars_here, ci0, lds + P.off_scan, metrics_slot);
     }
 #ifdef FTGP_WG_TIMES
     __syncthreads();
@@ -1315,8 +1375,10 @@ __global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(cons
 #endif
 }
 
-template __global__ void ftgp_step_kernel<false>(const DeviceParams*, int, int);
-template __global__ void ftgp_step_kernel<true>(const DeviceParams*, int, int);
+template __global__ void ftgp_step_kernel<false, false>(const DeviceParams*, int, int, int);
+template __global__ void ftgp_step_kernel<true, false>(const DeviceParams*, int, int, int);
+template __global__ void ftgp_step_kernel<false, true>(const DeviceParams*, int, int, int);
+template __global__ void ftgp_step_kernel<true, true>(const DeviceParams*, int, int, int);
 
 // K5 alone: one wave per car evaluates the driver on the scan stored in P.ranges (ftgp_policy_eval).
 __global__ void __launch_bounds__(256) ftgp_policy_kernel(DeviceParams P, int policy, double* __restrict__ ctrl_out)
@@ -1485,6 +1547,35 @@ __global__ void ftgp_box_field_kernel(const uint16_t* __restrict__ runx, const u
     uint32_t e = FTGP_FIELD_OUT;
     if (X >= 1 && X <= W && Y >= 1 && Y <= H) e = ftgp_box_entry(runx, runy, W, H, X - 1, Y - 1, sector);
     out[i] = (uint16_t)e;
+}
+
+// Exact Euclidean distance transform (FTGP_LIDAR_FAKELIDAR): out[y][x] = distance from pixel (x, y) to the nearest wall pixel,
+// centre to centre, 0 on walls -- scipy.ndimage.distance_transform_edt(~wall), the recipe of custom.py:1149-1153 / raycast.py:24-27.
+// runy[d][y][x] = wall-free run from the pixel along +y (d = 0) / -y (d = 1), 0 on walls, 65535 = to the image edge, so
+// g(x', y) = min of the two is the vertical distance to the nearest wall of column x'.  One pixel per lane walks its row outwards
+// from x until (x - x')^2 alone reaches the best squared distance: integers throughout, then one correctly rounded sqrt.
+__global__ void ftgp_edt_kernel(const uint16_t* __restrict__ runy, int W, int H, double* __restrict__ out)
+{
+    const size_t plane = (size_t)W * H;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= plane) return;
+    const int x = (int)(i % (size_t)W);
+    const uint16_t* up = runy + (i - x), * down = runy + plane + (i - x);       // the pixel's row in both planes
+    const long long INF = 1ll << 40;
+    long long best = INF;
+    for (int k = 0; k < W; ++k) {
+        const long long k2 = (long long)k * k;
+        if (k2 >= best) break;
+        for (int sgn = 0; sgn < (k ? 2 : 1); ++sgn) {
+            const int xp = sgn ? x + k : x - k;
+            if (xp < 0 || xp >= W) continue;
+            const int g = min((int)up[xp], (int)down[xp]);
+            if (g == 65535) continue;                                            // no wall in that column
+            const long long d2 = k2 + (long long)g * g;
+            best = d2 < best ? d2 : best;
+        }
+    }
+    out[i] = sqrt((double)best);
 }
 
 // Metrics record (FTGP_METRIC_DOUBLES): one block of 1024 threads (a handful of cars each: the records are 448 B apart, so the

@@ -66,6 +66,81 @@ def gather_metrics(env: capi.Env, comm: Optional[object] = None) -> np.ndarray:
     return comm.all_gather(env.metrics_local())
 
 
+class DeviceExchange:
+    """The end-of-launch metrics all-gather on the handle's own communicator (RCCL over xGMI; or a single rank), in two halves:
+    ``begin()`` right after a launch has been enqueued puts the exchange on the side stream behind that launch and returns at
+    once, ``end()`` waits for that exchange alone -- so the exchange of launch k runs beside launch k + 1."""
+    after_sync = False               # begin() wants the launch enqueued, not finished
+
+    def __init__(self, env: capi.Env):
+        self.env, self.open = env, False
+
+    def begin(self):
+        self.env.metrics_allgather_begin()
+        self.open = True
+
+    def end(self) -> np.ndarray:
+        self.open = False
+        return self.env.metrics_allgather_end()
+
+    def close(self):
+        pass
+
+
+class HostExchange:
+    """The same exchange over a host communicator (``Rendezvous`` or ``GlooGather``: anything with ``all_gather``): ``begin()``
+    -- after the launch has finished -- takes this rank's record (already in pinned memory) and hands it to a worker thread,
+    which gathers while the caller enqueues and runs the next launch; ``end()`` collects.  The worker never touches the
+    handle.  ``comm`` must not be used by the caller while an exchange is open (give the exchange a communicator of its own)."""
+    after_sync = True                # begin() needs the launch finished
+
+    def __init__(self, env: capi.Env, comm):
+        from concurrent.futures import ThreadPoolExecutor
+        self.env, self.comm, self.open = env, comm, False
+        self.pool = ThreadPoolExecutor(max_workers=1)
+        self.fut = None
+
+    def begin(self):
+        rec = self.env.metrics_local()
+        self.fut = self.pool.submit(self.comm.all_gather, rec)
+        self.open = True
+
+    def end(self) -> np.ndarray:
+        self.open = False
+        return self.fut.result()
+
+    def close(self):
+        self.pool.shutdown(wait=True)
+
+
+def run_timed(env: capi.Env, policy, steps: int, repeats: int, exchange, barrier=None, kernel_ms=None) -> Dict[str, object]:
+    """``repeats`` launches of exactly ``steps`` steps, each timed on its own (barrier, then wall clock from before the launch to
+    after its synchronisation).  The metrics exchange of launch k is begun inside launch k's timed region and collected inside
+    launch k + 1's, after that launch has been enqueued: it overlaps the next launch instead of sitting serially between two
+    (an exchange begun before the call -- the warm-up's -- is collected during the first launch).  The last launch's exchange is
+    collected after the loop.  ``kernel_ms()`` (default ``env.last_kernel_ms``) is what synchronises with a launch.
+    Returns {"wall_s": [...], "kernel_ms": [...], "records": the newest collected records}."""
+    sync = kernel_ms if kernel_ms is not None else env.last_kernel_ms
+    walls, kms, records = [], [], None
+    for _ in range(repeats):
+        if barrier is not None:
+            barrier()
+        t0 = time.perf_counter()
+        env.rollout(policy, steps)                       # enqueued: returns at once on the GPU
+        if exchange.open:
+            records = exchange.end()                     # the previous launch's exchange (it ran beside this enqueue / launch)
+        if not exchange.after_sync:
+            exchange.begin()                             # this launch's: side stream, behind the launch
+        k = sync()                                       # HIP events on the launch stream; also synchronises
+        if exchange.after_sync:
+            exchange.begin()                             # this launch's record to the worker thread
+        walls.append(time.perf_counter() - t0)
+        kms.append(float(k) if k is not None else float("nan"))
+    if exchange.open:
+        records = exchange.end()
+    return {"wall_s": walls, "kernel_ms": kms, "records": records}
+
+
 class Rendezvous:
     """All ranks of one job on one node: rank 0 listens, the others connect; every operation is a gather at rank 0
     followed by a broadcast (a few hundred bytes -- latency is irrelevant, ordering is what matters).
@@ -142,11 +217,13 @@ class Rendezvous:
                     time.sleep(0.05)
 
     @classmethod
-    def from_env(cls, timeout: float = 120.0) -> "Rendezvous":
-        """RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT as torch.distributed.run (or bench.py's own launcher) export them."""
+    def from_env(cls, timeout: float = 120.0, channel: str = "") -> "Rendezvous":
+        """RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT as torch.distributed.run (or bench.py's own launcher) export them.
+        ``channel`` names a second, independent connection set of the same job (e.g. for a ``HostExchange`` worker thread)."""
+        token = os.environ.get("TORCHELASTIC_RUN_ID", os.environ.get("FTGP_JOB_TOKEN", ""))
         return cls(int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
                    os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29500")),
-                   os.environ.get("TORCHELASTIC_RUN_ID", os.environ.get("FTGP_JOB_TOKEN", "")), timeout)
+                   (channel + ":" + token) if channel else token, timeout)
 
     @staticmethod
     def _recv_exact(c: socket.socket, n: int) -> bytes:

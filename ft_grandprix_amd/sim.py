@@ -8,9 +8,13 @@ What is mirrored (reference paths):
     ``speed, steering_angle = driver.process_lidar(...)``; an exception prints a message and leaves that
     car's previous controls in place -- custom.py:1395-1411,1421-1423
   * finished cars are handed the null driver -- custom.py:1367-1371,1446
-  * ``winners``: place of every finisher of a world, in the order cars reach ``lap_target`` -- custom.py:1125,1367-1369;
-    kept per env and derived from the device's finish step, so it is the same after one ``rollout()`` to the end of the race
-    as after stepping through it
+  * ``winners``: {vehicle id: place} of every finisher, in the order cars reach ``lap_target`` -- custom.py:1125,1367-1369 --
+    derived from the device's finish step, so it is the same after one ``rollout()`` to the end of the race as after stepping
+    through it.  With one world (``n_envs == 1``, the reference's case) it is exactly the reference's dict; with several it
+    holds every world's finishers under their global vehicle ids (places count per world) and ``winners_by_env[e]`` is world
+    e's own dict
+  * ``python -m ft_grandprix_amd.sim --cars template/cars/cars.json --track track --steps N``: the headless form of
+    ``python -m ft_grandprix.drive`` (drive.py:69-115: roster + track in, physics loop out)
   * ``reset()`` = Mujoco.reload(): drivers re-instantiated, race state cleared, cars re-spawned -- custom.py:1089-1128
 The physics / LiDAR / lap logic themselves run on the GPU behind ``capi.Env``.
 """
@@ -92,6 +96,7 @@ class VehicleState:
         self.good_start, self.finished, self.off_track = True, False, False
         self.speed, self.steering_angle = 0.0, 0.0
         self.times: List[float] = []
+        self.n_times = 0
 
     def lap_completion(self):
         return lap_completion(self.completion, self.good_start)
@@ -108,16 +113,18 @@ class Simulator:
     """Batched worlds with Python drivers: one ``Driver`` instance per car, called in car order every step."""
 
     def __init__(self, track: Track, cars: Sequence[dict], n_envs: int = 1, n_rays: int = 90, lap_target: int = 10,
-                 lib: Optional[capi.CLib] = None, spawn_mode: int = 0, seed: int = 1234, device_id: int = 0):
+                 lib: Optional[capi.CLib] = None, spawn_mode: int = 0, seed: int = 1234, device_id: int = 0,
+                 lidar_mode="rangefinder"):
         self.lib = lib if lib is not None else capi.load()
         self.cars = list(cars)
         self.env = capi.Env(self.lib, track, n_envs=n_envs, cars_per_env=len(self.cars), n_rays=n_rays,
-                            lap_target=lap_target, spawn_mode=spawn_mode, seed=seed, device_id=device_id)
+                            lap_target=lap_target, spawn_mode=spawn_mode, seed=seed, device_id=device_id, lidar_mode=lidar_mode)
         self.n_envs, self.cars_per_env, self.n_rays = n_envs, len(self.cars), n_rays
         self.timestep = self.env.dt
         self.steps = 0
         self.vehicle_states: List[VehicleState] = []
-        self.winners: List[dict] = [{} for _ in range(n_envs)]      # per env: {vehicle id: place}, custom.py:1125,1368-1369
+        self.winners: dict = {}                                      # {vehicle id: place}, custom.py:1125,1368-1369
+        self.winners_by_env: List[dict] = [{} for _ in range(n_envs)]
         self.reset()
 
     @staticmethod
@@ -139,7 +146,8 @@ class Simulator:
                                            label=car.get("name", f"car #{i}"), driver_path=path))
         self.vehicle_states = states
         self.steps = 0
-        self.winners = [{} for _ in range(self.n_envs)]
+        self.winners = {}
+        self.winners_by_env = [{} for _ in range(self.n_envs)]
         self._sync_race_state()
 
     def _sync_race_state(self):
@@ -150,9 +158,11 @@ class Simulator:
             p = prog[vs.id]
             vs.laps, vs.completion, vs.start, vs.delta = int(p[0]), int(p[1]), int(p[6]), int(p[8])
             vs.good_start, vs.off_track = bool(p[7]), bool(p[5])
-            vs.times = [float(t) for t in times[vs.id, : min(int(counts[vs.id]), capi.MAX_LAP_TIMES)]]
+            vs.times = capi.lap_time_list(counts[vs.id], times[vs.id])     # the newest MAX_LAP_TIMES of them, oldest first
+            vs.n_times = int(counts[vs.id])                                # len(times) in the reference (unbounded there)
             if p[4] and not vs.finished:           # custom.py:1367-1371 + 1446
-                self.winners[vs.id // self.cars_per_env][vs.id] = int(places[vs.id])
+                self.winners[vs.id] = int(places[vs.id])
+                self.winners_by_env[vs.id // self.cars_per_env][vs.id] = int(places[vs.id])
                 vs.finished = True
                 vs.driver = LobotomyDriver()
                 vs.v2 = False
@@ -195,9 +205,64 @@ class Simulator:
 
     def podium(self, env: int = 0) -> List[int]:
         """Vehicle ids of env's finishers, winner first (the order Mujoco.winners was filled in, custom.py:1368-1369)."""
-        w = self.winners[env]
+        w = self.winners_by_env[env]
         return sorted(w, key=w.get)
 
     def ranking(self) -> List[int]:
         """Car ids by absolute completion, best first (the dashboard order of custom.py:335)."""
         return [vs.id for vs in sorted(self.vehicle_states, key=lambda v: -v.absolute_completion())]
+
+
+def main(argv=None):
+    """Headless runner in the shape of the reference's legacy loop (``python -m ft_grandprix.drive``, drive.py:69-115): a roster
+    (template/cars/cars.json layout) and a track in, the physics loop out -- sense -> Driver.process_lidar -> ctrl -> step --
+    without the viewer and without the real-time sleep.  Prints one line per car at the end (and every --report steps)."""
+    import argparse
+    import os
+    import sys
+    from .track import load_track, load_track_from_template
+    ap = argparse.ArgumentParser(prog="python -m ft_grandprix_amd.sim", description=main.__doc__)
+    ap.add_argument("--cars", default=None, help="roster JSON: [{\"driver\": \"file://pkg/mod.py\" | \"pkg.mod\", \"name\": ...}, ...] "
+                                                 "(template/cars/cars.json); default: one car driven by --driver")
+    ap.add_argument("--driver", default="ft_grandprix_amd.drivers.follow_gap", help="driver module of the default one-car roster")
+    ap.add_argument("--track", default="track", help="name of a shipped track blob, or of <template-dir>/<name>.png + <name>-path.svg")
+    ap.add_argument("--template-dir", default=None, help="directory holding <track>.png and <track>-path.svg (the reference's template/)")
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--rays", type=int, default=90, help="rangefinders per car (custom.py:1158 uses 90)")
+    ap.add_argument("--envs", type=int, default=1, help="independent copies of the world (every copy runs the whole roster)")
+    ap.add_argument("--lap-target", type=int, default=10)
+    ap.add_argument("--device-policy", default=None, choices=("nidc", "fast", "lobotomy", "random"),
+                    help="run the whole loop on the device with this built-in driver for every car (ONE launch) instead of calling the roster's Python drivers")
+    ap.add_argument("--lidar", default="rangefinder", choices=("rangefinder", "fakelidar"))
+    ap.add_argument("--report", type=int, default=0, help="print the standings every this many steps")
+    args = ap.parse_args(argv)
+    sys.path.insert(0, os.getcwd())                      # roster entries are module paths relative to the working directory, as in the reference
+    roster = Simulator.load_roster(args.cars) if args.cars else [{"driver": args.driver, "name": "car #0"}]
+    track = load_track_from_template(args.template_dir, args.track) if args.template_dir else load_track(args.track)
+    sim = Simulator(track, roster, n_envs=args.envs, n_rays=args.rays, lap_target=args.lap_target, lidar_mode=args.lidar)
+
+    def standings():
+        for place, i in enumerate(sim.ranking(), 1):
+            vs = sim.vehicle_states[i]
+            fin = f" finished {ordinal(sim.winners[vs.id])}" if vs.finished else ""
+            print(f"{ordinal(place):>5}  {vs.label:<24} laps {vs.laps:3d}  completion {vs.lap_completion():4d} %  "
+                  f"lap times {[round(t, 3) for t in vs.times[-3:]]}{fin}")
+
+    try:
+        if args.device_policy:
+            sim.rollout(args.device_policy, args.steps)
+        else:
+            for k in range(args.steps):
+                sim.step()
+                if args.report and (k + 1) % args.report == 0:
+                    print(f"-- step {k + 1}")
+                    standings()
+        print(f"-- after {sim.steps} steps ({sim.steps * sim.timestep:.3f} s of simulated time)")
+        standings()
+    finally:
+        sim.close()
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FTGP_ABI_VERSION 3
+#define FTGP_ABI_VERSION 4
 
 /* status codes */
 #define FTGP_OK              0
@@ -43,8 +43,16 @@ extern "C" {
 #define FTGP_VEHICLE_MUSHR     0
 #define FTGP_VEHICLE_TRICYCLE  1
 
+/* what the rangefinders are (FtgpConfig.lidar_mode) */
+#define FTGP_LIDAR_RANGEFINDER 0  /* exact 2-D ray against the wall pixels and the other cars (template/mushr.em.xml:112-117,204-206 as read at
+                                     custom.py:1395) */
+#define FTGP_LIDAR_FAKELIDAR   1  /* the reference's own 2-D LiDAR: sphere tracing over the Euclidean distance transform of the track image,
+                                     ft_grandprix/raycast.py:5-21, wired as custom.py:1381-1393 (option use_simulated_simulation_lidar) */
+
 #define FTGP_PATH_POINTS   100   /* ft_grandprix/curve.py:8 */
-#define FTGP_MAX_LAP_TIMES  32   /* lap times kept per car (the oldest are kept; VehicleState.times is unbounded, lap_target defaults to 10, custom.py:124,961) */
+#define FTGP_MAX_LAP_TIMES  32   /* lap times kept per car: a ring of the NEWEST 32 -- lap time number k (0-based, in the order VehicleState.times
+                                    lists them, custom.py:124,1351-1363) sits in slot k % 32; the true count is kept beside it.  VehicleState.times
+                                    is unbounded; lap_target defaults to 10 (custom.py:961) */
 
 /* number of doubles / ints per car in the packed read-back rows */
 #define FTGP_SNAPSHOT_DOUBLES 10 /* laps, vel[3], yaw, pitch, roll, lap_completion, absolute_completion, time */
@@ -119,6 +127,22 @@ typedef struct FtgpConfig {
                                        collide with the walls -- here: four more wall-contact circles at the wheel positions */
     int32_t naive_flatten;          /* option "naive_flatten" (custom.py:981,1338-1339): re-projects the body quaternion onto pure yaw every
                                        step; the planar model has no pitch / roll, so this is accepted and changes nothing */
+    int32_t lidar_mode;             /* FTGP_LIDAR_RANGEFINDER (default) or FTGP_LIDAR_FAKELIDAR (option "use_simulated_simulation_lidar",
+                                       custom.py:987,1381-1393).  FAKELIDAR, per car and step, in binary64:
+                                         origin   i_x = (x / map_size) * width, i_y = -(y / map_size) * height of the car's position (custom.py:1382-1384)
+                                         ray j    image-frame direction (dxw, -dyw), (dxw, dyw) = R(yaw) * fan_dirs[j] -- ray order and orientation
+                                                  as the rangefinders' (index 0 = rear, counter-clockwise; the dead branch's own linspace,
+                                                  custom.py:1387, was never exercised: SURVEY.md 8a-3)
+                                         march    raycast.py:5-21 on the exact Euclidean distance transform of the wall image (the recipe of
+                                                  custom.py:1149-1153 / raycast.py:24-27, built at ftgp_create: integer squared distances, one sqrt)
+                                         range    (scan / width) * map_size (custom.py:1392-1393), stored as binary32
+                                       int() truncates toward zero and negative indices wrap like numpy's; a lookup past the right / bottom edge -- the
+                                       reference's IndexError -- ends the ray with range -1.  The rays see walls only (no other cars), as there. */
+    int32_t reserved2;
+    double map_size;                /* FAKELIDAR: world size of the map, 20 * scale = 40 (custom.py:1155,1382; mushr.em.xml:16-18); <= 0 means 40 */
+    const double *fan_dirs;         /* optional [n_rays][2]: body-frame unit directions of the rangefinder fan; NULL = the sites of
+                                       template/mushr.em.xml:112-117, (sin phi_j, -cos phi_j) with phi_j = radians(360 / n_rays * j - 90).
+                                       RANGEFINDER mode uses their binary32 roundings, FAKELIDAR mode the binary64 values. */
     FtgpTrack track;
     FtgpVehicle vehicle;
 } FtgpConfig;
@@ -199,7 +223,8 @@ int ftgp_get_progress(FtgpEnv *env, int32_t *out);
 /* int32[n_cars]: place of each car among the finishers of its env, 1 = winner, 0 = still racing (Mujoco.winners, custom.py:1125,1367-1369). */
 int ftgp_get_winners(FtgpEnv *env, int32_t *out);
 
-/* counts: int32[n_cars]; times: double[n_cars][FTGP_MAX_LAP_TIMES]; replaces VehicleState.times (custom.py:124,1351-1363). */
+/* counts: int32[n_cars] = len(VehicleState.times), the TRUE count; times: double[n_cars][FTGP_MAX_LAP_TIMES] = the ring of the newest
+ * 32 (lap time k in slot k % 32, see FTGP_MAX_LAP_TIMES); replaces VehicleState.times (custom.py:124,1351-1363). */
 int ftgp_get_lap_times(FtgpEnv *env, int32_t *counts, double *times);
 
 /* double[n_cars][2] current controls. */
@@ -234,6 +259,19 @@ int ftgp_metrics_local(FtgpEnv *env, double *out);
 int ftgp_comm_unique_id(uint8_t id_out[128]);
 int ftgp_comm_init(FtgpEnv *env, const uint8_t id[128], int rank, int world_size);
 int ftgp_metrics_allgather(FtgpEnv *env, double *out);
+/*
+ * The same exchange in two halves, so that it overlaps the next launch ("side stream, overlapped with the
+ * next step kernel"):
+ *   ftgp_metrics_allgather_begin : enqueues, behind the most recent ftgp_step / ftgp_rollout launch, the all-gather of the
+ *                                  record that launch leaves and the copy to pinned host memory -- on the side stream -- and
+ *                                  returns at once.  The caller may launch the next steps right away.
+ *   ftgp_metrics_allgather_end   : waits for that exchange only (never for a later launch) and copies the records out.
+ * The step kernel writes its record into one of two slots, alternating per launch; a launch that would reuse the slot of an
+ * exchange still in flight waits for it on the device.  At most one exchange may be open per handle (a second begin before
+ * the end is FTGP_ERR_STATE); ftgp_metrics_allgather() == begin + end.
+ */
+int ftgp_metrics_allgather_begin(FtgpEnv *env);
+int ftgp_metrics_allgather_end(FtgpEnv *env, double *out);
 
 /*
  * fakelidar-compatible 2-D sphere tracing (ft_grandprix/raycast.py:5-21), batched over origins, one ray per lane.
@@ -249,6 +287,10 @@ int ftgp_metrics_allgather(FtgpEnv *env, double *out);
  */
 int ftgp_fakelidar(int device_id, const double *dt, int H, int W, int n_origins, const double *origins, int rangefinders,
                    const double *cosines, const double *sines, double eps, double *scan, double *points);
+
+/* FAKELIDAR mode: the distance transform ftgp_create built, double[height][width] in pixels (what the reference calls self.dt,
+ * custom.py:1152-1153); FTGP_ERR_STATE in RANGEFINDER mode. */
+int ftgp_get_distance_field(FtgpEnv *env, double *out);
 
 /* Self-test of device arithmetic the kernels rely on (no reference counterpart): the fast reciprocal of the ray set-up against
  * the IEEE division of the specification over all 2^32 binary32 bit patterns.  *mismatches = number of differing results. */

@@ -10,6 +10,9 @@
  *   snapshot / euler .......... ft_grandprix/custom.py:149-160, 62-76, vehicle.py:3-12   [pinned: G4]
  *   reset / spawn ............. ft_grandprix/custom.py:1089-1128, 1232-1245, 81-87
  *   2-D sphere-traced LiDAR ... ft_grandprix/raycast.py:5-21                     [pinned: G2]
+ *   ... inside the step loop .. ft_grandprix/custom.py:1381-1393 (FtgpConfig.lidar_mode = FTGP_LIDAR_FAKELIDAR)   [pinned: G2 + G8]
+ *   distance transform ........ custom.py:1149-1153 / raycast.py:24-27 (scipy.ndimage.distance_transform_edt), restated
+ *                               without scipy: tests/test_oracle_golden.py compares it with scipy's on the four tracks
  *   drivers nidc / fast / lobotomy ... ft_grandprix/nidc.py:12-131, fast.py:11-139, lobotomy.py:1-3 [pinned: G1]
  *   vehicle + rangefinder model ..... template/mushr.em.xml:28-218 stepped by mujoco.mj_step
  *       (custom.py:1425).  MuJoCo (pinned 3.2.2 / 3.3.2 by requirements.txt:4 / uv.lock:104) is NOT
@@ -63,6 +66,7 @@ struct OracleEnv {
     uint8_t *field;          /* Chebyshev distance to the nearest wall cell, 0 on walls, clamped to 255 */
     float *ray_bx, *ray_by;  /* body-frame ray directions, binary32 */
     double *ray_bxd, *ray_byd;
+    double *edt;             /* FTGP_LIDAR_FAKELIDAR: Euclidean distance transform of the wall image (what the reference calls self.dt) */
     double spawn[NPATH][4];  /* x, y, qw, qz for a car spawned at path index p */
     int n_cars;
     Car *cars;
@@ -225,6 +229,67 @@ static void build_field(OracleEnv *e)
     free(d);
 }
 
+/* ------------------------------------------------------------------ exact Euclidean distance transform */
+/* custom.py:1149-1153 / raycast.py:24-27: dt = scipy.ndimage.distance_transform_edt(non-wall mask): for every pixel the distance,
+ * centre to centre, to the nearest wall pixel; 0 on walls.  Two separable passes on SQUARED distances: down every column the 1-D
+ * distance to the nearest wall of that column, then along every row the lower envelope of the parabolas (x - q)^2 + g(q)^2.  The
+ * envelope is built with exact integer arithmetic (parabola q takes over from p where x > ((g_q^2 + q^2) - (g_p^2 + p^2)) / (2 (q - p)),
+ * compared by cross-multiplication), so the squared distances are exact integers; dt = sqrt of them, correctly rounded. */
+static void build_edt(OracleEnv *e)
+{
+    const int W = e->cfg.track.width, H = e->cfg.track.height;
+    const int64_t INF = (int64_t)1 << 40;
+    int64_t *g2 = (int64_t *)malloc(sizeof(int64_t) * (size_t)W * H);
+    for (int x = 0; x < W; ++x) {
+        int64_t d = INF;                                   /* distance to the last wall seen above */
+        for (int y = 0; y < H; ++y) {
+            d = wall_at(e, x, y) ? 0 : (d >= INF ? INF : d + 1);
+            g2[(size_t)y * W + x] = d;
+        }
+        d = INF;
+        for (int y = H - 1; y >= 0; --y) {
+            d = wall_at(e, x, y) ? 0 : (d >= INF ? INF : d + 1);
+            if (d < g2[(size_t)y * W + x]) g2[(size_t)y * W + x] = d;
+        }
+    }
+    int *v = (int *)malloc(sizeof(int) * (size_t)W);       /* parabola sites of the envelope */
+    int64_t *zn = (int64_t *)malloc(sizeof(int64_t) * (size_t)(W + 1)), *zd = (int64_t *)malloc(sizeof(int64_t) * (size_t)(W + 1));
+    int64_t *f = (int64_t *)malloc(sizeof(int64_t) * (size_t)W);
+    for (int y = 0; y < H; ++y) {
+        int n = 0;
+        for (int q = 0; q < W; ++q) {
+            int64_t gq = g2[(size_t)y * W + q];
+            if (gq >= INF) continue;                       /* no wall in this column */
+            f[q] = gq * gq;
+            /* intersection of parabola q with the envelope's last one p: s = ((f_q + q^2) - (f_p + p^2)) / (2 (q - p)), kept as a fraction */
+            while (n > 0) {
+                int p = v[n - 1];
+                int64_t num = (f[q] + (int64_t)q * q) - (f[p] + (int64_t)p * p), den = 2 * (int64_t)(q - p);
+                /* s <= z[n-1]  <=>  num * zd <= zn * den  (all denominators positive) */
+                if (n > 1 && num * zd[n - 1] <= zn[n - 1] * den) { --n; continue; }
+                zn[n] = num; zd[n] = den;
+                break;
+            }
+            v[n] = q;
+            if (n == 0) { zn[0] = -INF; zd[0] = 1; }
+            ++n;
+        }
+        int k = 0;
+        for (int x = 0; x < W; ++x) {
+            double out;
+            if (n == 0) out = sqrt((double)INF);
+            else {
+                /* the parabola whose range contains x: advance while x > z[k + 1], i.e. x * zd > zn */
+                while (k + 1 < n && (int64_t)x * zd[k + 1] > zn[k + 1]) ++k;
+                int q = v[k];
+                out = sqrt((double)((int64_t)(x - q) * (x - q) + f[q]));
+            }
+            e->edt[(size_t)y * W + x] = out;
+        }
+    }
+    free(g2); free(v); free(zn); free(zd); free(f);
+}
+
 /* ------------------------------------------------------------------ K2: LiDAR */
 /* Ray against the other cars of the same env: chassis box and LiDAR puck (binary32). Returns +INF when nothing is hit. */
 static float ray_vs_cars(const OracleEnv *e, int car_index, double lcx, double lcy, float dxw, float dyw)
@@ -380,6 +445,43 @@ static double march_f64(const OracleEnv *e, double pu, double pv, double du, dou
     }
 }
 
+/* The reference's own 2-D LiDAR inside the step loop (option use_simulated_simulation_lidar, custom.py:987,1381-1393), statement by
+ * statement; the fan is the rangefinders' (ray order per SURVEY.md 8a-3: the branch's own linspace, custom.py:1387, is dead code). */
+static void fakelidar_car(OracleEnv *e, int ci)
+{
+    const FtgpConfig *c = &e->cfg;
+    const Car *a = &e->cars[ci];
+    const int R = c->n_rays, W = c->track.width, H = c->track.height;
+    float *out = e->ranges + (size_t)ci * R;
+    const double s = c->map_size > 0.0 ? c->map_size : 40.0;       /* s = 20 * self.map_metadata["scale"], custom.py:1382 */
+    const double i_x = (a->x / s) * (double)W;                      /* custom.py:1383 */
+    const double i_y = -(a->y / s) * (double)H;                     /* custom.py:1384 */
+    const double ch = 1.0 - 2.0 * (a->qz * a->qz), sh = 2.0 * (a->qw * a->qz);
+    for (int j = 0; j < R; ++j) {
+        const double dxw = ch * e->ray_bxd[j] - sh * e->ray_byd[j], dyw = sh * e->ray_bxd[j] + ch * e->ray_byd[j];
+        const double dx = dxw, dy = -dyw;                           /* image rows grow downwards */
+        /* raycast.py:9-20 */
+        double x = i_x, y = i_y, distance = 0;
+        int bad = 0;
+        long yi = (long)y, xi = (long)x;
+        if (yi < 0) yi += H;
+        if (xi < 0) xi += W;
+        double nearest = 0;
+        if (yi < 0 || yi >= H || xi < 0 || xi >= W) bad = 1; else nearest = e->edt[(size_t)yi * W + xi];
+        while (!bad && nearest > 2 && 0 <= x && x <= W && 0 <= y && y <= H) {
+            distance += nearest;
+            x += dx * nearest;
+            y += dy * nearest;
+            yi = (long)y; xi = (long)x;
+            if (yi < 0) yi += H;
+            if (xi < 0) xi += W;
+            if (yi < 0 || yi >= H || xi < 0 || xi >= W) { bad = 1; break; }    /* IndexError in the reference: the ray reads -1 here */
+            nearest = e->edt[(size_t)yi * W + xi];
+        }
+        out[j] = bad ? -1.0f : (float)((distance / (double)W) * s);             /* ranges /= original_width; ranges *= s (custom.py:1392-1393) */
+    }
+}
+
 static void lidar_car(OracleEnv *e, int ci)
 {
     const FtgpConfig *c = &e->cfg;
@@ -391,6 +493,7 @@ static void lidar_car(OracleEnv *e, int ci)
         for (int j = 0; j < R; ++j) out[j] = 0.0f;
         return;
     }
+    if (c->lidar_mode == FTGP_LIDAR_FAKELIDAR) { fakelidar_car(e, ci); return; }
     const double ch = 1.0 - 2.0 * (a->qz * a->qz), sh = 2.0 * (a->qw * a->qz);
     const double lcx = a->x + (ch * v->lidar_x - sh * v->lidar_y);
     const double lcy = a->y + (sh * v->lidar_x + ch * v->lidar_y);
@@ -459,7 +562,7 @@ static void progress_car(OracleEnv *e, int ci)
             if (a->n_times != 0) a->n_times -= 1;
         } else if (a->delta > 0) {
             if (a->good_start) {
-                if (a->n_times < FTGP_MAX_LAP_TIMES) a->times[a->n_times] = lap_time;
+                a->times[a->n_times % FTGP_MAX_LAP_TIMES] = lap_time;   /* times.append(lap_time); the newest FTGP_MAX_LAP_TIMES are kept */
                 a->n_times += 1;
                 a->start = (int32_t)steps;
             }
@@ -780,13 +883,19 @@ int oracle_create(const FtgpConfig *cfg, OracleEnv **out)
     e->cfg.track.bits = e->bits; e->cfg.track.path = &e->path[0][0];
     e->field = (uint8_t *)malloc((size_t)t->width * t->height);
     build_field(e);
+    e->cfg.fan_dirs = NULL;                               /* copied into ray_bxd / ray_byd below: the caller's buffer is not kept */
+    if (cfg->lidar_mode == FTGP_LIDAR_FAKELIDAR) {
+        e->edt = (double *)malloc(sizeof(double) * (size_t)t->width * t->height);
+        build_edt(e);
+    }
     const int R = cfg->n_rays;
     e->ray_bx = (float *)malloc(sizeof(float) * R); e->ray_by = (float *)malloc(sizeof(float) * R);
     e->ray_bxd = (double *)malloc(sizeof(double) * R); e->ray_byd = (double *)malloc(sizeof(double) * R);
     for (int j = 0; j < R; ++j) {
         /* mushr.em.xml:112-117: phi = radians(360/R*j - 90); ray = (sin phi, -cos phi) */
         double phi = ((360.0 / (double)R) * (double)j - 90.0) * (M_PI / 180.0);
-        e->ray_bxd[j] = sin(phi); e->ray_byd[j] = -cos(phi);
+        e->ray_bxd[j] = cfg->fan_dirs ? cfg->fan_dirs[2 * j] : sin(phi);
+        e->ray_byd[j] = cfg->fan_dirs ? cfg->fan_dirs[2 * j + 1] : -cos(phi);
         e->ray_bx[j] = (float)e->ray_bxd[j]; e->ray_by[j] = (float)e->ray_byd[j];
     }
     for (int p = 0; p < NPATH; ++p) {
@@ -822,7 +931,7 @@ int oracle_create(const FtgpConfig *cfg, OracleEnv **out)
 int oracle_destroy(OracleEnv *e)
 {
     if (!e) return 0;
-    free(e->bits); free(e->field); free(e->ray_bx); free(e->ray_by); free(e->ray_bxd); free(e->ray_byd);
+    free(e->edt); free(e->bits); free(e->field); free(e->ray_bx); free(e->ray_by); free(e->ray_bxd); free(e->ray_byd);
     free(e->cars); free(e->ranges); free(e->steps); free(e->place); free(e->n_winners); free(e);
     return 0;
 }
@@ -964,6 +1073,12 @@ int oracle_policy_eval(OracleEnv *e, int policy, const float *ranges, double *ct
     return 0;
 }
 int oracle_eval_progress(OracleEnv *e) { for (int i = 0; i < e->n_cars; ++i) progress_car(e, i); return 0; }
+int oracle_get_distance_field(OracleEnv *e, double *out)
+{
+    if (!e->edt) return fail(FTGP_ERR_STATE, "no distance field: lidar_mode is not FTGP_LIDAR_FAKELIDAR");
+    memcpy(out, e->edt, sizeof(double) * (size_t)e->cfg.track.width * e->cfg.track.height);
+    return 0;
+}
 int oracle_get_field(OracleEnv *e, uint8_t *out) { memcpy(out, e->field, (size_t)e->cfg.track.width * e->cfg.track.height); return 0; }
 
 int oracle_metrics_local(OracleEnv *e, double *out)
@@ -1037,7 +1152,7 @@ int oracle_progress_trace(int offset, int lap_target, double dt, int n, const in
                 double lap_time = (double)(s - a.start) * dt;
                 if (a.delta < 0) { a.laps -= 1; a.good_start = 0; if (a.n_times != 0) a.n_times -= 1; }
                 else if (a.delta > 0) {
-                    if (a.good_start) { if (a.n_times < FTGP_MAX_LAP_TIMES) a.times[a.n_times] = lap_time; a.n_times += 1; a.start = s; }
+                    if (a.good_start) { a.times[a.n_times % FTGP_MAX_LAP_TIMES] = lap_time; a.n_times += 1; a.start = s; }
                     a.laps += 1; a.good_start = 1;
                 }
             }

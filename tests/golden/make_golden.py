@@ -17,6 +17,11 @@ Fixtures (data only -- inputs and the reference's outputs):
   g7_bracket.json  ft_grandprix.bracket.Hasher(10).hash on sample strings; compute_driver_files() on a generated drivers
                    directory (the palette it used is stored as the function's input)
 
+  g8_fakelidar_step.npz  the reference's 2-D LiDAR as the step loop would call it (custom.py:1381-1393): ft_grandprix.raycast.fakelidar
+                   on scipy's distance transform (recipe of custom.py:1149-1153 / raycast.py:24-27) from car poses mapped to pixels with the
+                   expressions of custom.py:1382-1384, fan = the rangefinders' (SURVEY.md 8a-3), ranges scaled as custom.py:1392-1393;
+                   plus the SHA-256 of each track's distance transform
+
 custom.py imports mujoco / dearpygui / empy / svg.path, which are not installed; they are replaced by
 MagicMock entries in sys.modules for the import only -- none of the functions
 exercised here touches them.
@@ -328,9 +333,59 @@ def gen_g7():
     print("g7:", hashes, written)
 
 
+
+# ----------------------------------------------------------------------------- G8
+def gen_g8():
+    """Inputs are prepared with numpy's element-wise binary64 arithmetic (IEEE: one rounding per operation, what FtgpConfig.lidar_mode =
+    FTGP_LIDAR_FAKELIDAR specifies); everything from `fakelidar(...)` on is the reference's own code."""
+    from scipy.ndimage import distance_transform_edt
+    from ft_grandprix_amd.track import load_track_from_template
+    rng = np.random.default_rng(8)
+    data = {}
+    s = 20 * 2.0                                                    # s = 20 * map_metadata["scale"], custom.py:1155,1382
+    for name in ("track", "circle", "small-circle", "inkscape"):
+        t = load_track_from_template(os.path.join(REF, "template"), name)
+        W, H = t.width, t.height
+        balls = ~t.wall_mask()                                      # custom.py:1149-1151: 0 on pure-white pixels, non-zero elsewhere
+        dt = distance_transform_edt(balls)                          # custom.py:1152-1153, raycast.py:27
+        data[f"{name}_edt_sha256"] = np.frombuffer(hashlib.sha256(np.ascontiguousarray(dt, dtype=np.float64).tobytes()).digest(), dtype=np.uint8)
+        n = 16
+        idx = rng.choice(100, n, replace=False)
+        xy = t.path[idx] + rng.uniform(-0.1, 0.1, (n, 2))
+        yaw = rng.uniform(-np.pi, np.pi, n)
+        qw0, qz0 = np.cos(yaw / 2), np.sin(yaw / 2)
+        nrm = np.sqrt(qw0 * qw0 + qz0 * qz0)                        # ftgp_set_pose normalises the quaternion
+        qw, qz = qw0 / nrm, qz0 / nrm
+        data[f"{name}_xy"], data[f"{name}_quat"] = xy, np.stack([qw0, qz0], axis=1)
+        ch, sh = 1.0 - 2.0 * (qz * qz), 2.0 * (qw * qz)
+        i_x = (xy[:, 0] / s) * W                                    # custom.py:1383
+        i_y = -(xy[:, 1] / s) * H                                   # custom.py:1384
+        for R in (36, 1080):
+            phi = ((360.0 / R) * np.arange(R) - 90.0) * (np.pi / 180.0)     # mushr.em.xml:112-117
+            fan = np.stack([np.sin(phi), -np.cos(phi)], axis=1)
+            data[f"fan_{R}"] = fan
+            scan = np.zeros((n, R)); rngs = np.zeros((n, R), dtype=np.float32)
+            for k in range(n):
+                dxw = ch[k] * fan[:, 0] - sh[k] * fan[:, 1]
+                dyw = sh[k] * fan[:, 0] + ch[k] * fan[:, 1]
+                ranges, _ = raycast.fakelidar(i_x[k], i_y[k], dt, R, dxw, -dyw)
+                scan[k] = ranges
+                ranges = ranges.copy()
+                ranges /= W                                         # custom.py:1392 (original_width)
+                ranges *= s                                         # custom.py:1393
+                rngs[k] = ranges.astype(np.float32)
+            data[f"{name}_{R}_scan"], data[f"{name}_{R}_ranges"] = scan, rngs
+    np.savez_compressed(os.path.join(HERE, "g8_fakelidar_step.npz"), **data)
+    print("g8: ok")
+
+
 if __name__ == "__main__":
+    if "--only-g8" in sys.argv:
+        gen_g8()
+        raise SystemExit(0)
     gen_g6()
     gen_g7()
+    gen_g8()
     if "--only-new" in sys.argv:
         raise SystemExit(0)
     gen_g1()

@@ -29,6 +29,7 @@ def load_oracle():
     d.oracle_set_lidar_mode.argtypes = [C.c_void_p, C.c_int]
     d.oracle_set_threads.argtypes = [C.c_void_p, C.c_int]
     d.oracle_get_field.argtypes = [C.c_void_p, C.c_void_p]
+    d.oracle_get_distance_field.argtypes = [C.c_void_p, C.c_void_p]
     return lib
 
 

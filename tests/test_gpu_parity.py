@@ -468,6 +468,58 @@ def test_rccl_communicator_single_rank(product):
         assert rec[0][0] == 8 * 40 and rec[0][1] == 8
 
 
+@pytest.mark.parametrize("with_comm", [False, True])
+def test_metrics_exchange_in_two_halves_beside_the_next_launch(product, with_comm):
+    """ftgp_metrics_allgather_begin / _end (side stream, overlapped with the next step kernel), with a one-rank RCCL
+    communicator (the real ncclAllGather on the side stream) and without one: the exchange begun behind launch k is collected
+    after launch k + 1 -- even k + 2 -- has been enqueued and still delivers launch k's record; this rank's own record
+    (ftgp_metrics_local) is never overwritten by gathered ones (rank > 0 read rank 0's record from the shared buffer)."""
+    t = load_track("circle")
+    with capi.Env(product, t, n_envs=8, n_rays=36, spawn_mode=1) as g, capi.Env(product, t, n_envs=8, n_rays=36, spawn_mode=1) as twin:
+        if with_comm:
+            g.comm_init(capi.comm_unique_id(product), 0, 1)
+        g.rollout("nidc", 40); twin.rollout("nidc", 40)
+        g.metrics_allgather_begin()
+        with pytest.raises(capi.FtgpError) as ei:
+            g.metrics_allgather_begin()                  # one exchange at a time
+        assert ei.value.code == -4
+        g.rollout("nidc", 30)                            # launch k + 1: the other record slot
+        g.rollout("nidc", 30)                            # launch k + 2: launch k's slot again -- waits on the device for the open exchange
+        rec = g.metrics_allgather_end()
+        np.testing.assert_array_equal(rec[0], twin.metrics_local())          # launch k's record (40 steps), not a later one
+        assert rec[0][0] == 8 * 40
+        with pytest.raises(capi.FtgpError):
+            g.metrics_allgather_end()                    # nothing open
+        twin.rollout("nidc", 60)
+        np.testing.assert_array_equal(g.metrics_local(), twin.metrics_local())             # the newest state: 100 steps
+        np.testing.assert_array_equal(g.metrics_allgather()[0], twin.metrics_local())      # begin + end in one call
+        np.testing.assert_array_equal(g.metrics_local(), twin.metrics_local())             # ... which leaves this rank's record alone
+        g.reset(); twin.reset()                          # no launch has produced this state's record: the metrics kernel does
+        g.metrics_allgather_begin()
+        np.testing.assert_array_equal(g.metrics_allgather_end()[0], twin.metrics_local())
+        np.testing.assert_array_equal(g.lidar(), twin.lidar())
+
+
+def test_bench_repeats_median_and_overlap_fields(product):
+    """The bench line of a short launch: several launches timed one by one, the median reported, `repeats` in the line, the
+    roofline's `bound` derived from the committed counters with both fractions side by side."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "20", "--warmup", "5", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["repeats"] >= 5 and d["repeats"] % 2 == 1 and d["steps"] == 20
+    assert d["ms_per_step_best"] <= d["ms_per_step"] <= d["ms_per_step_worst"]
+    assert d["value"] == pytest.approx(4096 / (d["ms_per_step"] * 1e-3), rel=1e-9)
+    r = d["roofline"]
+    assert r["frac"] == r["frac_hbm"] == pytest.approx(r["achieved"] / 8000.0)
+    assert r["bound"] in ("hbm", "valu-issue") and (r["bound"] == "hbm" or r["frac_valu_busy"] > 0.6)
+    assert r["kernel_ms_per_launch"] * d["repeats"] < 1e3
+    assert d["metrics_allgather"]["sum_steps"] == 4096 * (5 + 20 * d["repeats"])       # the record collected last is the last launch's
+
+
 @pytest.mark.parametrize("name", ["track", "circle", "small-circle", "inkscape"])
 def test_g2_fakelidar_on_gpu_bit_exact(product, name):
     """Row a3: the fakelidar-compat kernel against the outputs of the reference's own raycast.fakelidar (fixture G2)."""
@@ -636,14 +688,14 @@ def test_bench_two_ranks_host_gather():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["FTGP_BENCH_COLLECTIVE"] = "host"
-    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--envs-per-gpu", "256"],
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--envs-per-gpu", "256", "--repeats", "3"],
                        env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 5 and d["scaling"] == "weak" and "cpu_baseline" not in d
-    assert d["metrics_allgather"]["ranks"] == 2 and d["metrics_allgather"]["sum_steps"] == 2 * 256 * (2 + 5)
+    assert d["repeats"] == 3 and d["metrics_allgather"]["ranks"] == 2 and d["metrics_allgather"]["sum_steps"] == 2 * 256 * (2 + 3 * 5)
     assert d["value"] == pytest.approx(2 * 256 * 5 / (d["ms_per_step"] * 5e-3), rel=1e-6)
 
 

@@ -224,3 +224,89 @@ def test_bench_gpus_2_without_a_gpu_fails_loudly():
                        env=env, capture_output=True, text=True, timeout=120)
     assert p.returncode != 0
     assert p.stderr.count("needs a HIP device") >= 1 and p.stdout.strip() == ""
+
+
+# ---------------------------------------------------------------- the exchange overlaps the next launch
+class _SlowComm:
+    """A host communicator whose gather takes `delay` seconds more (the stand-in for a slow collective)."""
+
+    def __init__(self, comm, delay):
+        self.comm, self.delay, self.calls = comm, delay, 0
+
+    def all_gather(self, rec):
+        self.calls += 1
+        time.sleep(self.delay)
+        return self.comm.all_gather(rec)
+
+
+def _overlap_main(rank, world, port, q):
+    """One rank: the oracle stands in for the GPU (a `launch` is a blocking CPU rollout), the metrics travel over a Rendezvous of
+    their own inside a HostExchange worker thread.  Timed twice: plain gather, and a gather slowed by most of a launch."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), FTGP_JOB_TOKEN="t-overlap")
+    sys.path.insert(0, ROOT)
+    from tests.helpers import load_oracle
+    rdzv = ftdist.Rendezvous.from_env(timeout=60)
+    rdzv_x = ftdist.Rendezvous.from_env(timeout=60, channel="x")
+    try:
+        ora = load_oracle()
+        t = load_track("circle")
+        with ftdist.make_shard(ora, t, 8, rank, world, n_rays=90, spawn_mode=1, seed=5) as sh:
+            t0 = time.perf_counter(); sh.rollout("nidc", 40); per_step = (time.perf_counter() - t0) / 40
+            steps = max(20, int(0.25 / per_step))                       # a launch of about a quarter of a second
+            steps = int(rdzv.max([steps])[0])
+            out = {}
+            for label, delay in (("plain", 0.0), ("slow", 0.2)):
+                comm = _SlowComm(rdzv_x, delay)
+                ex = ftdist.HostExchange(sh, comm)
+                sh.rollout("nidc", steps); ex.begin()                   # the warm-up launch and its exchange
+                timed = ftdist.run_timed(sh, "nidc", steps, 4, ex, rdzv.barrier, kernel_ms=lambda: None)
+                ex.close()
+                walls = rdzv.max(timed["wall_s"])
+                out[label] = (walls.tolist(), timed["records"], sh.metrics_local(), comm.calls)
+            q.put((rank, steps, out))
+    finally:
+        rdzv_x.close(); rdzv.close()
+
+
+def test_metrics_exchange_overlaps_the_next_launch_two_ranks(oracle):
+    """Two ranks, host gather standing in for the collective: a gather slowed by 0.2 s -- most of a launch -- must not lengthen
+    the launches it runs beside (serial, every launch would take 0.2 s longer), and the records collected at the end are the
+    last launch's, from every rank, in rank order."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_overlap_main, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs: p.start()
+    out = sorted((q.get(timeout=300) for _ in procs), key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for label in ("plain", "slow"):
+        recs0, recs1 = out[0][2][label][1], out[1][2][label][1]
+        np.testing.assert_array_equal(recs0, recs1)                                   # every rank holds every rank's record
+        np.testing.assert_array_equal(recs0[0], out[0][2][label][2])                  # ... of the LAST launch (nothing ran since)
+        np.testing.assert_array_equal(recs0[1], out[1][2][label][2])
+        assert out[0][2][label][3] == 5                                               # warm-up + 4 timed launches: one exchange each
+    plain, slow = np.median(out[0][2]["plain"][0]), np.median(out[0][2]["slow"][0])
+    assert slow < plain + 0.1, (plain, slow)            # serial would be plain + 0.2
+
+
+def test_run_timed_device_exchange_order(oracle):
+    """The call order ftdist.run_timed imposes on a DeviceExchange-like object: launch k is enqueued, THEN exchange k - 1 is
+    collected, THEN exchange k is begun, THEN the launch is synchronised -- never two exchanges open, none left open."""
+    log = []
+
+    class Env:
+        def rollout(self, policy, steps): log.append("launch")
+        def last_kernel_ms(self): log.append("sync"); return 1.0
+
+    class Ex:
+        after_sync, open = False, False
+        def begin(self): assert not self.open; self.open = True; log.append("begin")
+        def end(self): assert self.open; self.open = False; log.append("end"); return "rec"
+
+    ex = Ex(); ex.begin()                                # the warm-up's exchange
+    r = ftdist.run_timed(Env(), "fast", 20, 3, ex, barrier=lambda: log.append("barrier"))
+    assert log == ["begin"] + ["barrier", "launch", "end", "begin", "sync"] * 3 + ["end"]
+    assert r["records"] == "rec" and len(r["wall_s"]) == 3 and r["kernel_ms"] == [1.0] * 3

@@ -117,10 +117,26 @@ def test_simulator_winners_are_per_env_and_survive_a_rollout(oracle):
     sim.rollout("nidc", 18000)
     w = sim.env.winners()
     for e in range(8):
-        assert sim.winners[e] == {e * 4 + i: int(w[e, i]) for i in range(4) if w[e, i]}
+        assert sim.winners_by_env[e] == {e * 4 + i: int(w[e, i]) for i in range(4) if w[e, i]}
         assert sim.podium(e) == [e * 4 + i for i in np.argsort(np.where(w[e] > 0, w[e], 99)) if w[e, i]]
+    # the reference-shaped dict {vehicle id: place} (custom.py:1125,1368-1369) holds every world's finishers under their ids
+    assert sim.winners == {vs.id: int(w[vs.id // 4, vs.id % 4]) for vs in sim.vehicle_states if w[vs.id // 4, vs.id % 4]}
     assert all(vs.finished == bool(w[vs.id // 4, vs.id % 4]) for vs in sim.vehicle_states)
     assert sim.steps == 18000
+    sim.close()
+
+
+def test_simulator_winners_is_the_reference_dict_for_one_world(oracle):
+    """n_envs == 1 is the reference's case: ``winners[id]`` is the place of vehicle id (custom.py:1125,1368-1369)."""
+    t = load_track("circle")
+    cars = [{"driver": "ft_grandprix_amd.sim", "name": f"car {i}"} for i in range(4)]
+    sim = Simulator(t, cars, n_envs=1, n_rays=90, lap_target=1, lib=oracle, spawn_mode=1, seed=5)
+    spread_race(sim.env, t)
+    sim.rollout("nidc", 18000)
+    w = sim.env.winners()[0]
+    assert w.max() >= 1
+    assert isinstance(sim.winners, dict) and sim.winners == {i: int(w[i]) for i in range(4) if w[i]}
+    assert sim.winners == sim.winners_by_env[0]
     sim.close()
 
 

@@ -8,7 +8,7 @@ other than "latest" names the files sq_<tag>.json, ... and leaves the files benc
   traffic_latest.json              FETCH_SIZE / WRITE_SIZE of the step kernel, separate --pmc passes (guide: KB; FETCH x2 on gfx950)
 Every rocprofv3 command starts the python program directly (no shell / env hop) as a child of this orchestrator, which never
 touches the GPU itself."""
-import csv, glob, hashlib, json, os, shutil, subprocess, sys
+import csv, glob, hashlib, json, os, re, shutil, subprocess, sys
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 os.chdir(ROOT)
@@ -23,12 +23,8 @@ RAYS = 1080
 os.environ.setdefault("TMPDIR", "/tmp")
 
 
-def sha():
-    h = hashlib.sha256()
-    for rel in ("ft_grandprix_amd/csrc/ftgp_kernels.hip", "ft_grandprix_amd/csrc/ftgp_march.h", "ft_grandprix_amd/csrc/ftgp_device.h",
-                "ft_grandprix_amd/csrc/ftgp_api.hip", "include/ftgp.h"):
-        h.update(open(rel, "rb").read())
-    return h.hexdigest()[:16]
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from evidence import sha, code_object_meta        # noqa: E402  (one definition of "the sources' hash", shared with bench.py's check)
 
 
 def run(cmd, log, timeout=400):
@@ -50,14 +46,24 @@ def pmc(tag, counters):
     for r in rows:
         if int(r["Dispatch_Id"]) == last:
             c[r["Counter_Name"]] = c.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
-            meta = {"kernel": r["Kernel_Name"], "vgpr": r.get("VGPR_Count") or r.get("Arch_VGPR_Count"), "scratch_bytes_per_lane": r.get("Scratch_Size"),
-                    "lds_bytes": r.get("LDS_Block_Size"), "grid": r.get("Grid_Size"), "workgroup": r.get("Workgroup_Size")}
-    ms = [l for l in open(f"{OUT}/raw_{tag}.log").read().splitlines() if l.startswith("kernel ms")]
+            meta = {"kernel": r["Kernel_Name"], "grid": r.get("Grid_Size"), "workgroup": r.get("Workgroup_Size")}
+    text = open(f"{OUT}/raw_{tag}.log").read()
+    ms = [l for l in text.splitlines() if l.startswith("kernel ms")]
     meta["kernel_ms"] = float(ms[-1].split()[2]) if ms else None
+    # registers / scratch from the code object's own metadata, the dynamic LDS from ftgp_create (FTGP_VERBOSE): rocprofv3's VGPR_Count and
+    # LDS_Block_Size columns read 32 and 0 for this kernel (63 registers, ~73 KB of dynamic LDS)
+    for k, v in KERNEL_META.items():
+        if k in meta.get("kernel", ""):
+            meta.update(v)
+    lds = re.findall(r"(\d+) cars x (\d+) waves per workgroup, (\d+) B of LDS", text)
+    if lds:
+        meta["cars_per_workgroup"], meta["waves_per_workgroup"], meta["dynamic_lds_bytes"] = (int(x) for x in lds[-1])
     return c, meta
 
 
 os.makedirs(OUT, exist_ok=True)
+os.environ["FTGP_VERBOSE"] = "1"
+KERNEL_META = code_object_meta()
 base = {"config": f"{ENVS} envs x {CARS} car(s) x {RAYS} rays, {TRACK}, {POLICY}, {STEPS} steps per launch", "track": TRACK, "steps": STEPS, "n_envs": ENVS, "n_rays": RAYS, "cars": CARS,
         "policy": POLICY, "kernel_source_sha": sha()}
 
@@ -91,7 +97,7 @@ tr["algorithmic_bytes_per_env_step"] = CARS * (4 * RAYS + 832)
 json.dump(tr, open(f"{OUT}/traffic_{TAG}.json", "w"), indent=1)
 
 # 3. the bench line reads these two files: give it the ones of this very visit (same sources, so nothing is "stale")
-PROFILES = "profiles/round3"
+PROFILES = "profiles/round4"
 os.makedirs(PROFILES, exist_ok=True)
 for name in (f"sq_{TAG}.json", f"traffic_{TAG}.json"):
     shutil.copy(f"{OUT}/{name}", f"{PROFILES}/{name}")
@@ -102,10 +108,12 @@ SUFFIX = "" if TAG == "latest" else "_" + TAG
 run(["python3", "bench.py", "--steps", str(STEPS), "--warmup", "50", *cfg] + ([] if TAG == "latest" else ["--no-cpu-baseline"]), f"{OUT}/bench{SUFFIX}.log", 600)
 line = [l for l in open(f"{OUT}/bench{SUFFIX}.log").read().splitlines() if l.startswith("{")][-1]
 open(f"{OUT}/bench{SUFFIX}.json", "w").write(line + "\n")
+open(f"{OUT}/bench{SUFFIX}.json.sha", "w").write(sha() + "\n")
 shutil.rmtree(f"{OUT}/raw_stats", ignore_errors=True)
 run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", f"{OUT}/raw_stats", "--",
      "python3", "bench.py", "--steps", str(STEPS), "--warmup", "50", "--no-cpu-baseline", *cfg], f"{OUT}/raw_stats.log", 600)
 shutil.copy(glob.glob(f"{OUT}/raw_stats/**/*kernel_stats.csv", recursive=True)[0], f"{OUT}/kernel_stats{SUFFIX}.csv")
+open(f"{OUT}/kernel_stats{SUFFIX}.csv.sha", "w").write(sha() + "\n")
 
 for d in glob.glob(f"{OUT}/raw_*"):
     if os.path.isdir(d):
