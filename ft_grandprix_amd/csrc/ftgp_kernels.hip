@@ -385,6 +385,24 @@ __device__ __forceinline__ void lidar_pool(const DeviceParams& P, ScalarParams G
                                     "global_load_ushort %1, %2, %9" FTGP_FIELD_LOAD_MOD "\n\ts_waitcnt vmcnt(0)"
                                     : "+v"(s_in), "+v"(w), "=&v"(off)
                                     : "v"(ray.iy), "v"(ray.ay), "v"(ray.offC), "v"(ray.ix), "v"(ray.ax), "v"(ray.s), "s"(field));
+#ifdef FTGP_PAD_EXEC        // diagnostic (tools/half_exec.sh, never in the product): 16 filler instructions per march iteration with all 64 lanes
+            // enabled (FTGP_PAD_EXEC = 0), with lanes 32..63 disabled (1) or with lanes 0..31 disabled (2) -- does a wave64 vector instruction
+            // whose one half is empty issue in one pass instead of two?  The mask is saved, changed and restored INSIDE one asm
+            // statement: nothing the compiler schedules can land between the two writes of exec.  (Round 3's version wrote exec_hi in
+            // separate statements; the compiler moved two instructions of the march -- the SDWA adds that form the box's far corner --
+            // between them, lanes 32..63 kept a stale corner, and the next field load of those lanes faulted.)
+            {   int pad0 = lane, pad1 = lane + 1; int pad_save;
+#define FTGP_PAD_F2 FTGP_PAD_EXEC_ASM("%0") "\n\t" FTGP_PAD_EXEC_ASM("%1") "\n\t"
+#define FTGP_PAD_F16 FTGP_PAD_F2 FTGP_PAD_F2 FTGP_PAD_F2 FTGP_PAD_F2 FTGP_PAD_F2 FTGP_PAD_F2 FTGP_PAD_F2 FTGP_PAD_F2
+#if FTGP_PAD_EXEC == 1
+                asm volatile("s_mov_b32 %2, exec_hi\n\ts_mov_b32 exec_hi, 0\n\t" FTGP_PAD_F16 "s_mov_b32 exec_hi, %2\n\ts_nop 1" : "+v"(pad0), "+v"(pad1), "=&s"(pad_save) : "v"(lane), "s"(live_mask) : "vcc");
+#elif FTGP_PAD_EXEC == 2
+                asm volatile("s_mov_b32 %2, exec_lo\n\ts_mov_b32 exec_lo, 0\n\t" FTGP_PAD_F16 "s_mov_b32 exec_lo, %2\n\ts_nop 1" : "+v"(pad0), "+v"(pad1), "=&s"(pad_save) : "v"(lane), "s"(live_mask) : "vcc");
+#else
+                asm volatile("s_mov_b32 %2, exec_hi\n\ts_nop 0\n\t" FTGP_PAD_F16 "s_nop 0\n\ts_nop 1" : "+v"(pad0), "+v"(pad1), "=&s"(pad_save) : "v"(lane), "s"(live_mask) : "vcc");
+#endif
+            }
+#endif
 #ifdef FTGP_PAD_VALU        // diagnostic (tools/valu_cost.sh): FTGP_PAD_VALU independent filler instructions per march iteration; what one more costs
             {   int pad0 = lane, pad1 = lane + 1; unsigned long long padm; double padd0 = 1.0, padd1 = 2.0;
                 #pragma unroll

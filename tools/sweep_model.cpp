@@ -54,8 +54,17 @@ int main(int argc, char** argv)
     Tables g; build(bits, W, H, wpr, g);
     const size_t cells = (size_t)ftgp_plane256(W, H) * 128;
     std::vector<uint16_t> field(cells * FTGP_SECTORS, (uint16_t)FTGP_FIELD_OUT);
-    for (int oct = 0; oct < FTGP_SECTORS; ++oct) for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x)
-        field[(size_t)oct * cells + (size_t)(y + 1) * (W + 2) + (x + 1)] = (uint16_t)BOX_ENTRY(g.runx.data(), g.runy.data(), W, H, x, y, oct);
+    {   // the field is cached between runs of the model (it only depends on the track and the sector count)
+        char cache[256]; snprintf(cache, sizeof cache, "/tmp/sweep_model_field_%dx%d_%d.bin", W, H, FTGP_SECTORS);
+        FILE* cf = fopen(cache, "rb");
+        if (cf && fread(field.data(), 2, field.size(), cf) == field.size()) fclose(cf);
+        else {
+            #pragma omp parallel for collapse(2) schedule(dynamic, 8)
+            for (int oct = 0; oct < FTGP_SECTORS; ++oct) for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x)
+                field[(size_t)oct * cells + (size_t)(y + 1) * (W + 2) + (x + 1)] = (uint16_t)BOX_ENTRY(g.runx.data(), g.runy.data(), W, H, x, y, oct);
+            cf = fopen(cache, "wb"); if (cf) { fwrite(field.data(), 2, field.size(), cf); fclose(cf); }
+        }
+    }
     const int fstride = W + 2; const uint32_t plane256 = ftgp_plane256(W, H);
     std::vector<float> bx(R), by(R);
     for (int j = 0; j < R; ++j) { const double phi = ((360.0 / R) * j - 90.0) * (M_PI / 180.0); bx[j] = (float)sin(phi); by[j] = (float)(-cos(phi)); }
@@ -111,6 +120,8 @@ int main(int argc, char** argv)
         std::stable_sort(k5.begin(), k5.end());
         for (int c = 0; c < n_cars; ++c) for (int j = 0; j < R; ++j) perm[c][j] = k5[j].second;
     }
+    const int iso_mode = getenv("ISO") ? atoi(getenv("ISO")) : 0;
+    long iso_used = 0, iso_near = 0;
     struct Lane { FtgpRay r; int g; bool done; };
     for (int c0 = 0; c0 < n_cars; c0 += cpb) {
         const int nc = std::min(cpb, n_cars - c0), total = nc * R;
@@ -141,6 +152,26 @@ int main(int argc, char** argv)
                             const float du = dxw * isx, dv = -(dyw * isy);
                             ftgp_ray_init(l.r, fmaf(du, -r0, u0), fmaf(dv, -r0, v0), du, dv, fabsf(1.0f / du), fabsf(1.0f / dv), W, H, fstride, plane256);
                             l.done = false;
+                            if (iso_mode) {          // what-if: a first jump without a lookup, by the clearance of the LiDAR centre (one value per car)
+                                // D = distance (pixels) from the centre to the nearest wall pixel or image edge, margin sqrt(2) + slack
+                                const int cx = (int)floorf(u0), cy = (int)floorf(v0);
+                                double D = 1e9;
+                                const int RAD = 80;
+                                for (int yy = std::max(0, cy - RAD); yy <= std::min(H - 1, cy + RAD); ++yy) for (int xx = std::max(0, cx - RAD); xx <= std::min(W - 1, cx + RAD); ++xx)
+                                    if (g.wall[(size_t)yy * W + xx]) { const double ddx = xx + 0.5 - u0, ddy = yy + 0.5 - v0; D = std::min(D, sqrt(ddx * ddx + ddy * ddy)); }
+                                D = std::min(D, (double)RAD);
+                                D = std::min(D, std::min(std::min((double)u0, (double)W - u0), std::min((double)v0, (double)H - v0)));
+                                if (iso_mode == 2) D = floor(D);                    // as a u8 plane would hold it
+                                const float t0 = (float)((D - 1.5) / std::max(isx, isy));
+                                if (t0 > r0) {
+                                    const float lx = fmaf(du, t0, u0), ly = fmaf(dv, t0, v0);
+                                    const float fx = lx - floorf(lx), fy = ly - floorf(ly);
+                                    if (fabsf(fx - 0.5f) <= 0.5f - eps && fabsf(fy - 0.5f) <= 0.5f - eps) {
+                                        const int mxm = du < 0 ? -1 : 0, mym = dv < 0 ? -1 : 0;
+                                        l.r.ix = (int)floorf(lx) ^ mxm; l.r.iy = (int)floorf(ly) ^ mym; ++iso_used;
+                                    } else ++iso_near;
+                                }
+                            }
                             if (getenv("PRESTEP")) {          // what-if: the start cell's entry is at hand (no wave-iteration for it)
                                 const uint32_t wq = field[ftgp_ray_offset(l.r) >> 1];
                                 FtgpStep st; const bool near = ftgp_ray_step(l.r, wq, eps, st);
@@ -182,5 +213,6 @@ int main(int argc, char** argv)
            "max wave-iters per WG %.1f  128B-lines per wave-iter %.1f\n",
            R, cpb, wpb, refill, (int)-log2f(eps), wave_iters / nsteps, refills / nsteps, fixes / nsteps, lane_iters / nsteps, lane_iters / (64.0 * wave_iters),
            (double)lane_iters / rays, (double)max_wave_iters_sum / ((n_cars + cpb - 1) / cpb), (double)lines / wave_iters);
+    if (iso_mode) printf("ISO: %ld rays started past their origin cell, %ld fell back (landing near a boundary)\n", iso_used, iso_near);
     return 0;
 }
