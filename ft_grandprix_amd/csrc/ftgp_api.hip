@@ -444,6 +444,10 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
     { hipDeviceProp_t prop; CREATE_TRY(hipGetDeviceProperties(&prop, e->device)); P.n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256; }
     P.edge_margin = (float)(v.lidar_ring_radius * std::max(P.inv_px_x, P.inv_px_y) * 1.001 + 2.0);
     P.ray_magic = (uint32_t)((0x100000000ull + (uint64_t)cfg->n_rays - 1) / (uint64_t)cfg->n_rays);
+    P.groups_per_car = (cfg->n_rays + FTGP_WAVE - 1) / FTGP_WAVE;
+    P.group_magic = P.groups_per_car == 1 ? 0u : (uint32_t)((0x100000000ull + (uint64_t)P.groups_per_car - 1) / (uint64_t)P.groups_per_car);     // 0: one group per car, the group IS the car
+    for (uint32_t g = 0; P.group_magic && g < (uint32_t)(FTGP_MAX_CARS_PER_BLOCK * P.groups_per_car + 64); ++g)      // group index -> car slot by multiplication: exact for every index the sweep can draw
+        if ((uint32_t)(((uint64_t)g * P.group_magic) >> 32) != g / (uint32_t)P.groups_per_car) { ftgp_destroy(e); return fail(FTGP_ERR_ARG, "internal: group_magic is not exact%s"); }
 
     // workgroup shape: whole envs, at most 16 cars (K1 / K3 run on the lanes of one wave), two workgroups per CU
     // (<= 80 KiB of LDS each) so that 8 waves per SIMD hide the latency of the field loads

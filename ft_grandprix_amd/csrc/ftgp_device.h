@@ -77,6 +77,8 @@ struct DeviceParams {
     const double* fan_dirs;       // [n_rays][2] body-frame fan directions, binary64
     double map_size;              // 20 * scale = 40 (custom.py:1382)
     int32_t lidar_mode, pad_e;
+    int32_t groups_per_car;       // ceil(n_rays / 64): the sweep hands out groups of 64 consecutive rays of one car (lidar_groups)
+    uint32_t group_magic;         // ceil(2^32 / groups_per_car): group index -> car slot without a division
     const uint16_t* field;        // [FTGP_SECTORS][height + 2][width + 2] box entries (ftgp_march.h), HBM/L2
     const uint32_t* bits;         // [height][words_per_row] wall bitmap
     const uint32_t* nearbits;     // [height][words_per_row] wall bitmap dilated by contact_reach (early-out of the wall contact)

@@ -43,8 +43,8 @@ struct Lds {
     int64_t* steps;
     float* scan;              // [2][cars_per_block][win_floats] scan windows (layout: scan_window_* below), double-buffered by step parity
     int* list;                // [waves_per_block][64] driver scratch
-    int* pool;                // [2] next ray of the sweep, [2] drivers finished, [2] "some LiDAR frame is not known to lie well inside the image"
-                              // (frame_write) -- all double-buffered by step parity
+    int* pool;                // [2] next ray group (lidar_groups) / next ray (lidar_pool) of the sweep, [2] drivers finished, [2] "some LiDAR frame is
+                              // not known to lie well inside the image" (frame_write) -- all double-buffered by step parity
     Force* terms;             // [cars_per_block][FTGP_FORCE_TERMS] K1 staging: force terms in the order they are summed
     double* wnew;             // [cars_per_block][4] K1 staging: new wheel spins
     Dyn* next;                // [cars_per_block] K1 staging: new dynamic state before the commit
@@ -136,6 +136,9 @@ __device__ __forceinline__ Lds lds_view(const LdsOffsets& o, unsigned char* lds)
 // per refill, rank among the free lanes via ballot/popcount).  Which lane marches which ray has no influence on any result.
 #ifndef FTGP_PAD_ASM
 #define FTGP_PAD_ASM "v_add_u32 %0, %0, %3"
+#endif
+#ifndef FTGP_FIELD_LOAD_MOD
+#define FTGP_FIELD_LOAD_MOD ""        // cache-policy bits of the field load (A/B in profiles/round3/ab_field_load.log: none is best)
 #endif
 #ifndef FTGP_REFILL
 #define FTGP_REFILL (MULTI ? 60 : 48)     // measured optimum (tools/ab.sh): the multi-car refill also runs the inter-vehicle tests
@@ -370,15 +373,35 @@ __device__ __forceinline__ void lidar_pool(const DeviceParams& P, ScalarParams G
         const int want = pool_empty ? FTGP_WAVE : FTGP_REFILL;
         uint32_t w = FTGP_FIELD_OUT;
         bool alive = cj >= 0;            // lanes whose ray is known to sit on its terminal cell keep that cell's entry and issue no load
+#ifdef FTGP_NO_GUARD
+        for (;;) {
+#else
         for (int guard = 0; guard < 4 * 8192; ++guard) {
+#endif
+#ifdef FTGP_PAD_SALU        // diagnostic: FTGP_PAD_SALU scalar filler instructions per march iteration -- is the scalar unit a limit?
+            {   int spad = 0;
+                #pragma unroll
+#if !defined(FTGP_PAD_SALU_KIND) || FTGP_PAD_SALU_KIND == 0
+#define FTGP_PAD_SALU_ASM "s_add_u32 %0, %0, 1"
+#elif FTGP_PAD_SALU_KIND == 1
+#define FTGP_PAD_SALU_ASM "s_nop 0"
+#elif FTGP_PAD_SALU_KIND == 2
+#define FTGP_PAD_SALU_ASM "s_and_b64 vcc, vcc, exec"
+#elif FTGP_PAD_SALU_KIND == 3
+#define FTGP_PAD_SALU_ASM "s_waitcnt lgkmcnt(0)"
+#elif FTGP_PAD_SALU_KIND == 4
+#define FTGP_PAD_SALU_ASM "s_cbranch_execz 0"
+#elif FTGP_PAD_SALU_KIND == 5
+#define FTGP_PAD_SALU_ASM "s_mov_b32 %0, 7"
+#endif
+                for (int q = 0; q < FTGP_PAD_SALU; ++q) asm volatile(FTGP_PAD_SALU_ASM : "+s"(spad) : : "scc", "vcc");
+            }
+#endif
             // a finished ray idles: it issues no load (w keeps its terminal cell's entry, so st.live stays false).  The crossing
             // time into the cell that is looked up is put aside under the load's mask (s_in: a move where there is a mask anyway)
             // -- for the lookup that ends the ray that is its range -- and the ray's cell and time, never used again, are left
             // to drift: no select holds them.  (Running the whole body under the mask of the unfinished lanes instead was
             // measured 4 % slower: the divergent control flow costs more than the selects it saves.)
-#ifndef FTGP_FIELD_LOAD_MOD
-#define FTGP_FIELD_LOAD_MOD ""        // cache-policy bits of the field load (A/B in profiles/round3/ab_field_load.log: none is best)
-#endif
             // (one statement: entry offset = ftgp_ray_offset(), the move, the load -- the compiler pads between separate ones)
             int off;
             if (alive) asm volatile("v_mad_i32_i24 %2, %3, %4, %5\n\tv_mad_i32_i24 %2, %6, %7, %2\n\tv_mov_b32 %0, %8\n\t"
@@ -426,6 +449,171 @@ __device__ __forceinline__ void lidar_pool(const DeviceParams& P, ScalarParams G
         // a finished ray has just looked its terminal cell up once more: w is that cell's entry
         done = !alive;
         hit = w == 0u;
+    }
+}
+
+// The march of one wave's rays until ALL of them sit on their terminal cell: hand-written, because what limits this kernel is the
+// number of instructions a SIMD can issue -- of ANY kind: scalar, branch and wait instructions cost about as much as a cheap vector
+// instruction (profiles/round4/salu_cost.log) -- and the compiler's loop spends 13 scalar-side instructions per iteration on mask
+// bookkeeping.  Here a lane leaves the loop by dropping out of exec (v_cmpx on "the cell's entry is a box", i.e. kx != 0), so the
+// body needs no live mask, finished rays hold their cell and crossing time for free (and burn no vector lanes), and the loop
+// closes with one branch on exec: 21 vector + 4 scalar-side instructions per iteration, + the near-boundary path.
+// In: exec = the lanes that hold a ray; ix, iy = (mirrored) cell, s = crossing time into it (0 at the origin).
+// Out: w = entry of the terminal cell (0 = wall, FTGP_FIELD_OUT = ring), s = crossing time into it, exec as on entry.
+// The arithmetic is ftgp_ray_step / ftgp_ray_fix / ftgp_ray_commit of ftgp_march.h, instruction for instruction.
+__device__ __forceinline__ void march_all(int& ix, int& iy, float& s, uint32_t& w, float pum, float pvm, float ivx, float ivy, float dum, float dvm,
+                                          int offC, int ax, int ay, float thr /* 0.5f - eps */, const void* field)
+{
+    int a, b, c, d, e, f, g, h, i;
+    uint64_t stepx, sv, sq, ex0;
+    asm volatile(
+        "s_mov_b64 %[ex0], exec\n"
+        "L_march_loop_%=:\n\t"
+        "v_mad_i32_i24 %[a], %[iy], %[ay], %[offC]\n\t"
+        "v_mad_i32_i24 %[a], %[ix], %[ax], %[a]\n\t"
+        "global_load_ushort %[w], %[a], %[field]\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        "v_add_u32_sdwa %[c], %[ix], %[w] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"     // xe = ix + kx
+        "v_add_u32_sdwa %[d], %[iy], %[w] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t"     // ye = iy + ky
+        "v_cmpx_ne_u32_e32 vcc, %[c], %[ix]\n\t"                         // kx == 0: wall or ring cell -- the lane is done
+        "s_cbranch_execz L_march_done_%=\n\t"
+        "v_cvt_f32_i32_e32 %[a], %[c]\n\t"
+        "v_cvt_f32_i32_e32 %[b], %[d]\n\t"
+        "v_sub_f32_e32 %[a], %[a], %[pum]\n\t"
+        "v_sub_f32_e32 %[b], %[b], %[pvm]\n\t"
+        "v_mul_f32_e32 %[a], %[ivx], %[a]\n\t"                           // sX = ((float)xe - pum) * ivx
+        "v_mul_f32_e32 %[b], %[ivy], %[b]\n\t"                           // sY = ((float)ye - pvm) * ivy
+        "v_cmp_lt_f32_e64 %[stepx], %[a], %[b]\n\t"                      // the x edge of the box is reached first (a tie steps in y)
+        "v_fma_f32 %[e], %[dvm], %[a], %[pvm]\n\t"                       // landing estimate after an x-jump ...
+        "v_fma_f32 %[f], %[dum], %[b], %[pum]\n\t"                       // ... after a y-jump
+        "v_cndmask_b32_e64 %[g], %[b], %[a], %[stepx]\n\t"               // sn
+        "v_cndmask_b32_e64 %[e], %[f], %[e], %[stepx]\n\t"               // v
+        "v_cvt_flr_i32_f32_e32 %[h], %[e]\n\t"                           // t = floor(v)
+        "v_fract_f32_e32 %[f], %[e]\n\t"
+        "v_add_f32_e32 %[f], -0.5, %[f]\n\t"
+        "v_cmp_gt_f32_e64 vcc, |%[f]|, %[thr]\n\t"                       // within eps of a pixel boundary: the specification's comparisons decide
+        "s_cbranch_vccnz L_march_fix_%=\n"
+        "L_march_commit_%=:\n\t"
+        "v_cndmask_b32_e64 %[ix], %[h], %[c], %[stepx]\n\t"
+        "v_cndmask_b32_e64 %[iy], %[d], %[h], %[stepx]\n\t"
+        "v_mov_b32_e32 %[s], %[g]\n\t"
+        "s_branch L_march_loop_%=\n"
+        "L_march_fix_%=:\n\t"                                            // ftgp_ray_fix() for the lanes in vcc
+        "s_and_saveexec_b64 %[sv], vcc\n\t"
+        "v_cndmask_b32_e64 %[a], %[pum], %[pvm], %[stepx]\n\t"           // transverse origin ...
+        "v_cndmask_b32_e64 %[b], %[ivx], %[ivy], %[stepx]\n\t"           // ... reciprocal ...
+        "v_cndmask_b32_e64 %[f], %[ix], %[iy], %[stepx]\n\t"             // ... current cell ...
+        "v_cndmask_b32_e64 %[i], %[c], %[d], %[stepx]\n\t"
+        "v_add_u32_e32 %[i], -1, %[i]\n\t"                               // ... last cell of the box's span
+        "v_rndne_f32_e32 %[e], %[e]\n\t"                                 // the boundary in doubt
+        "v_sub_f32_e32 %[a], %[e], %[a]\n\t"
+        "v_mul_f32_e32 %[a], %[b], %[a]\n\t"                             // its crossing time, the specification's way
+        "v_cvt_i32_f32_e32 %[b], %[e]\n\t"
+        "v_cmp_lt_f32_e64 vcc, %[a], %[g]\n\t"
+        "v_cmp_le_f32_e64 %[sq], %[a], %[g]\n\t"
+        "s_and_b64 %[sq], %[sq], %[stepx]\n\t"                           // crossed: S <= sn after an x-jump, S < sn after a y-jump
+        "s_or_b64 vcc, vcc, %[sq]\n\t"
+        "v_cndmask_b32_e64 %[a], -1, 0, vcc\n\t"
+        "v_add_u32_e32 %[h], %[b], %[a]\n\t"                             // the cell beyond the boundary if crossed, else the one before
+        "v_med3_i32 %[h], %[h], %[f], %[i]\n\t"                          // inside the box's span
+        "s_mov_b64 exec, %[sv]\n\t"
+        "s_branch L_march_commit_%=\n"
+        "L_march_done_%=:\n\t"
+        "s_mov_b64 exec, %[ex0]"
+        : [ix] "+v"(ix), [iy] "+v"(iy), [s] "+v"(s), [w] "+v"(w),
+          [a] "=&v"(a), [b] "=&v"(b), [c] "=&v"(c), [d] "=&v"(d), [e] "=&v"(e), [f] "=&v"(f), [g] "=&v"(g), [h] "=&v"(h), [i] "=&v"(i),
+          [stepx] "=&s"(stepx), [sv] "=&s"(sv), [sq] "=&s"(sq), [ex0] "=&s"(ex0)
+        : [pum] "v"(pum), [pvm] "v"(pvm), [ivx] "v"(ivx), [ivy] "v"(ivy), [dum] "v"(dum), [dvm] "v"(dvm),
+          [offC] "v"(offC), [ax] "v"(ax), [ay] "v"(ay), [thr] "s"(thr), [field] "s"(field)
+        : "vcc", "scc", "memory");
+}
+
+// The sweep of one step for all cars of the workgroup, by every wave, in GROUPS of 64 consecutive rays of one car: a wave takes the
+// next group (one LDS atomic), sets its 64 rays up, marches them until all have finished (march_all), stores the 64 ranges, and takes
+// the next group.  Nothing is handed out ray by ray: no ranks, no per-lane bookkeeping, no partial refills -- the price is that a
+// group lasts as long as its slowest ray (lane utilisation 0.61 against 0.78 with batched refills, tools/sweep_model.cpp), paid in
+// lanes that sit masked out, not in instructions: a set-up costs about 60 instructions per 64 rays against 150 per 52, an
+// iteration 25 against 35.  Rays of a group are neighbours: they share field lines, and their ranges leave as one row segment.
+template <bool MULTI>
+__device__ __forceinline__ void lidar_groups(const DeviceParams& P, ScalarParams G, const Lds& L, const LidarFrame* frames, const PairCull* pairs, float* scan_rows, int* pool,
+                                             int ncars_here, int ci0, bool scan_lds, bool second_half STAMP_ARG)
+{
+    typedef __attribute__((address_space(1))) float* global_f32;
+    typedef __attribute__((address_space(1))) unsigned char* global_u8w;
+    const int R = G->n_rays, gpc = G->groups_per_car, ngroups = ncars_here * gpc;
+    const int W = G->width, H = G->height, fstride = G->fstride, stride = G->ranges_stride;
+    const uint32_t plane256 = G->plane256, gmagic = G->group_magic;
+    const int eighth = G->eighth, win_floats = G->win_floats;
+    const float isx = G->inv_px_x_f, isy = G->inv_px_y_f, thr = 0.5f - G->snap_eps;
+    const float r0 = sgpr(L.veh->ring_radius_f);
+    const void* field = G->field;
+    const global_f32 ranges = (global_f32)G->ranges + (size_t)ci0 * stride;
+    const int cars_per_env = G->cars_per_env;
+    const int lane = lane_here();
+    const bool all_safe = sgpr(pool[4]) == 0;        // every ray of this sweep starts on the image (frame_write): no test per ray
+    sweep_priority(second_half);
+    for (int round = 0; round < (1 << 16); ++round) {          // (bounded: a safety net)
+        STAMP(ta);
+        int g = 0;
+        if (lane == 0) g = atomicAdd(pool, 1);
+        g = __builtin_amdgcn_readfirstlane(g);
+        if (g >= ngroups) break;
+        const int c = gmagic ? (int)__umulhi((uint32_t)g, gmagic) : g, j0 = (g - c * gpc) * FTGP_WAVE;      // car slot, first ray (wave-uniform)
+        const int j = j0 + lane;
+        FtgpRay ray;
+        uint32_t w = FTGP_FIELD_OUT;
+        float dxw = 0.0f, dyw = 0.0f;
+        const bool mine = j < R;                     // the last group of a car is short
+        if (mine) {
+            const float4 f4 = *reinterpret_cast<const float4*>(frames + c);      // u0, v0, chf, shf (one address for the wave)
+            const float2 bd = L.ray[j];
+            dxw = fmaf(f4.z, bd.x, -(f4.w * bd.y));
+            dyw = fmaf(f4.w, bd.x, f4.z * bd.y);
+            const float du = dxw * isx;
+            const float dv = -(dyw * isy);
+            const float pu = fmaf(du, -r0, f4.x);
+            const float pv = fmaf(dv, -r0, f4.y);
+            float ivx, ivy;
+            rcp_abs2(du, dv, ivx, ivy);
+            ray.result = -1.0f;
+            ftgp_ray_init(ray, pu, pv, du, dv, ivx, ivy, W, H, fstride, plane256, true, &P.sector_tab[0][0]);
+            if (!all_safe) {             // wave-uniform, rare: some car of the workgroup is near the image edge, off it, or has finished
+                ftgp_ray_park_if_outside(ray, pu, pv, W, H);
+                // a finished car's rangefinders are switched off (custom.py:1436-1439): its frame carries u0 = -inf, so the ray is
+                // parked like any ray that starts off the image, and reads 0 instead of -1
+                ray.result = (f4.x == -INFINITY) ? 0.0f : -1.0f;
+            }
+            STAMP(tb); STAMP_ADD(8, tb - ta); STAMP_ADD(9, 1);
+            march_all(ray.ix, ray.iy, ray.s, w, ray.pum, ray.pvm, ray.ivx, ray.ivy, ray.dum, ray.dvm, ray.offC, ray.ax, ray.ay, thr, field);
+            STAMP(tc); STAMP_ADD(10, tc - tb);
+            float r = (w == 0u) ? fabsf(ray.s) : ray.result;        // ftgp_ray_range()
+            if (MULTI) {
+                // Rays also see the other cars of the env (a9).  One record per env-mate (PairCull, written with the frames) rules a
+                // mate out with a dot product: it can only be touched if it lies in front of the ray and within `cull` of its line.
+                const PairCull* mates = pairs + c * FTGP_PAIR_STRIDE;
+                const int slot0 = sgpr(frames[c].slot0);
+                for (int k = 0; k < cars_per_env; ++k) {
+                    const float4 q = *reinterpret_cast<const float4*>(mates + k);
+                    const float al = fmaf(q.x, dxw, q.y * dyw);
+                    if (al >= q.z) {
+                        const float cull = L.veh->cull_radius;
+                        if (r >= 0.0f && (al + r0) - cull > r) continue;             // the mate lies beyond the wall hit
+                        const float rc = ray_vs_car(L.veh, frames + slot0 + k, q.x, q.y, dxw, dyw);
+                        if (rc < INFINITY && (r < 0.0f || rc < r)) r = rc;
+                    }
+                }
+            }
+            // the on-device drivers read ranges[0] and ranges[eighth : n - eighth]: that window is kept in LDS and goes to HBM as whole
+            // lines once the sweep is over (window_flush); everything else leaves now, 64 consecutive floats per wave
+            const int jw = j - eighth;
+            const bool in_window = scan_lds && (unsigned)jw < (unsigned)(R - 2 * eighth);
+            if (!in_window) *(global_f32)((global_u8w)(ranges + c * stride) + ((uint32_t)j << 2)) = r;
+            if (scan_lds) {
+                float* row = scan_rows + c * win_floats;
+                if (in_window) row[(eighth & 3) + jw] = r;
+                if (j0 == 0 && lane == 0) row[win_floats - 1] = r;
+            }
+        }
     }
 }
 
@@ -1360,7 +1548,11 @@ __global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(cons
             const DeviceParams& P = *reinterpret_cast<const DeviceParams*>(lds + off.params);
             const Lds L = lds_view(off, lds);
             if (FAKE) lidar_fake(G, L.frame + par * cpb, L.scan + par * cpb * G->win_floats, ncars_here, ci0, need_scan, wave, nwaves);
+#ifdef FTGP_SWEEP_V1
             else lidar_pool<MULTI>(P, G, L, L.frame + par * cpb, L.pairs + par * cpb * FTGP_PAIR_STRIDE, L.scan + par * cpb * G->win_floats, L.pool + par, ncars_here, ci0, need_scan, second_half STAMP_PASS);
+#else
+            else lidar_groups<MULTI>(P, G, L, L.frame + par * cpb, L.pairs + par * cpb * FTGP_PAIR_STRIDE, L.scan + par * cpb * G->win_floats, L.pool + par, ncars_here, ci0, need_scan, second_half STAMP_PASS);
+#endif
         }
 #endif
         STAMP(t4);

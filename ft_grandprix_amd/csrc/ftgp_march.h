@@ -97,6 +97,7 @@ FTGP_HD uint32_t ftgp_plane256(int W, int H) { return (2u * (uint32_t)(W + 2) * 
 // comparisons decide.  With unit roundoff u = 2^-24 the estimate fl(p + d * s) is off by at most u * M and the specification's
 // crossing time ((float)b - p) * (1 / d) by a relative 3u, i.e. by at most 3u * M pixels (M = largest coordinate); twice that
 // bound, on the next power of two of M:  eps = 2 * 4u * M = 2^-21 * pow2ceil(max(W, H) + 2).
+// (The factor 2 is a safety margin on top of a rigorous bound: the power of two above M already leaves 1.0 .. 2.0 x.)
 FTGP_HD float ftgp_snap_eps(int W, int H)
 {
     const int m = (W > H ? W : H) + 2;
@@ -275,19 +276,21 @@ FTGP_HD bool ftgp_ray_step(const FtgpRay& r, uint32_t w, float eps, FtgpStep& st
     return st.live & (fabsf(frac - 0.5f) > 0.5f - eps);    // within eps of a boundary (and never for a NaN)
 }
 
-// the specification's comparisons for a landing point close to a boundary (sY(b) <= s after an x-jump, sX(b) < s after a y-jump),
-// inside the transverse span [cur, hi] of the box
+// The specification's comparison for a landing point close to a boundary.  "Close" means within eps of ONE pixel boundary -- the
+// nearest integer to the estimate -- and eps is far below half a pixel, so that boundary is the only one in doubt: has the ray
+// crossed it by the time sn of the jump (sY(b) <= sn after an x-jump, sX(b) < sn after a y-jump: a tie steps in y first)?  The cell
+// is the one beyond it if so, the one before it if not, kept inside the transverse span [cur, hi] of the box.
 FTGP_HD int ftgp_ray_fix(const FtgpRay& r, const FtgpStep& st)
 {
     const float tp = st.stepx ? r.pvm : r.pum, tinv = st.stepx ? r.ivy : r.ivx;
     const int cur = st.stepx ? r.iy : r.ix, hi = (st.stepx ? st.ye : st.xe) - 1;
-    int t = st.t;
+    const float v = st.stepx ? fmaf(r.dvm, st.sn, r.pvm) : fmaf(r.dum, st.sn, r.pum);     // the landing estimate of ftgp_ray_step()
+    const float bf = rintf(v);                                // nearest boundary (ties cannot occur here: the fraction is within eps of 0 or 1)
+    const float S = (bf - tp) * tinv;
+    const bool crossed = st.stepx ? (S <= st.sn) : (S < st.sn);
+    int t = (int)bf - (crossed ? 0 : 1);
     t = t < cur ? cur : t; t = t > hi ? hi : t;
-    const float Sa = ((float)t - tp) * tinv, Sb = ((float)(t + 1) - tp) * tinv;
-    const bool ca = st.stepx ? (Sa <= st.sn) : (Sa < st.sn), cb = st.stepx ? (Sb <= st.sn) : (Sb < st.sn);
-    const bool dec = (t > cur) & !ca;
-    const bool inc = !dec & (t < hi) & cb;
-    return t + (inc ? 1 : 0) - (dec ? 1 : 0);
+    return t;
 }
 
 // Second half.  With hold (the default) a finished ray stays on its terminal cell and keeps the crossing time into it.
