@@ -25,7 +25,7 @@ def sha():
 def stamp(path):
     text = open(path, errors="replace").read()
     if text.startswith("# kernel_source_sha="):
-        text = text.split("\n", 1)[1] if "\n" in text else ""
+        return                                         # stamped when it was measured (e.g. by tools/ab_pmc.sh): never re-stamp after the fact
     open(path, "w").write(f"# kernel_source_sha={sha()} {time.strftime('%Y-%m-%d %H:%M:%S')} {os.path.basename(path)}\n" + text)
 
 
