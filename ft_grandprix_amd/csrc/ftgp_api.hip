@@ -6,7 +6,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "ftgp_kernels.hip"
@@ -445,9 +447,7 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
     P.edge_margin = (float)(v.lidar_ring_radius * std::max(P.inv_px_x, P.inv_px_y) * 1.001 + 2.0);
     P.ray_magic = (uint32_t)((0x100000000ull + (uint64_t)cfg->n_rays - 1) / (uint64_t)cfg->n_rays);
     P.groups_per_car = (cfg->n_rays + FTGP_WAVE - 1) / FTGP_WAVE;
-    P.group_magic = P.groups_per_car == 1 ? 0u : (uint32_t)((0x100000000ull + (uint64_t)P.groups_per_car - 1) / (uint64_t)P.groups_per_car);     // 0: one group per car, the group IS the car
-    for (uint32_t g = 0; P.group_magic && g < (uint32_t)(FTGP_MAX_CARS_PER_BLOCK * P.groups_per_car + 64); ++g)      // group index -> car slot by multiplication: exact for every index the sweep can draw
-        if ((uint32_t)(((uint64_t)g * P.group_magic) >> 32) != g / (uint32_t)P.groups_per_car) { ftgp_destroy(e); return fail(FTGP_ERR_ARG, "internal: group_magic is not exact%s"); }
+    if (P.groups_per_car > FTGP_MAX_GROUPS) { ftgp_destroy(e); return fail(FTGP_ERR_ARG, "n_rays above 16384 is not supported%s"); }
 
     // workgroup shape: whole envs, at most 16 cars (K1 / K3 run on the lanes of one wave), two workgroups per CU
     // (<= 80 KiB of LDS each) so that 8 waves per SIMD hide the latency of the field loads
@@ -478,6 +478,21 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
                 ftgp_destroy(e);
                 return FTGP_ERR_ARG;
             }
+    }
+    {   // the sweep's work list: group draw g -> (kidx = g / cars_per_block, car slot = g % cars_per_block), group = group_order[kidx]
+        const uint32_t cpbu = (uint32_t)P.cars_per_block;
+        P.group_magic = cpbu == 1 ? 0u : (uint32_t)((0x100000000ull + cpbu - 1) / cpbu);
+        for (uint32_t g = 0; P.group_magic && g < cpbu * (uint32_t)P.groups_per_car + 64; ++g)
+            if ((uint32_t)(((uint64_t)g * P.group_magic) >> 32) != g / cpbu) { ftgp_destroy(e); return fail(FTGP_ERR_ARG, "internal: group_magic is not exact%s"); }
+        // expected march length of a group ~ how far its rays look along the car's axis: |cos| of the angle between the group's middle ray
+        // and the axis (ray 0 looks backwards, ray n/2 ahead); ties keep index order
+        std::vector<std::pair<double, int>> key;
+        for (int k = 0; k < P.groups_per_car; ++k) {
+            const double mid = std::min((double)cfg->n_rays - 1.0, 64.0 * k + 31.5);
+            key.push_back({ -fabs(cos(2.0 * M_PI * mid / (double)cfg->n_rays)), k });
+        }
+        std::stable_sort(key.begin(), key.end());
+        for (int k = 0; k < P.groups_per_car; ++k) P.group_order[k] = getenv("FTGP_GROUP_ORDER_PLAIN") ? k : key[(size_t)k].second;
     }
     CREATE_TRY(hipFuncSetAttribute((const void*)ftgp_step_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     CREATE_TRY(hipFuncSetAttribute((const void*)ftgp_step_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -6,6 +6,7 @@
 #include "ftgp_march.h"
 
 #define FTGP_WAVE 64
+#define FTGP_MAX_GROUPS 256              // groups of 64 rays per car: n_rays <= 16384
 #define FTGP_MAX_CARS_PER_BLOCK 16      // K1 / K3 run one car per lane group of a single wave: 16 cars x 4 lanes
 
 // Per-car state, array-of-structs in HBM.  The step kernel keeps CarCore in LDS for the whole launch.
@@ -78,7 +79,7 @@ struct DeviceParams {
     double map_size;              // 20 * scale = 40 (custom.py:1382)
     int32_t lidar_mode, pad_e;
     int32_t groups_per_car;       // ceil(n_rays / 64): the sweep hands out groups of 64 consecutive rays of one car (lidar_groups)
-    uint32_t group_magic;         // ceil(2^32 / groups_per_car): group index -> car slot without a division
+    uint32_t group_magic;         // ceil(2^32 / cars_per_block) (0 for one car per block): group draw -> (rank of the group, car slot) without a division
     const uint16_t* field;        // [FTGP_SECTORS][height + 2][width + 2] box entries (ftgp_march.h), HBM/L2
     const uint32_t* bits;         // [height][words_per_row] wall bitmap
     const uint32_t* nearbits;     // [height][words_per_row] wall bitmap dilated by contact_reach (early-out of the wall contact)
@@ -101,6 +102,8 @@ struct DeviceParams {
     alignas(16) int32_t sector_tab[FTGP_SECTORS][4];     // ftgp_sector_entry() of every sector (staged into LDS with the head of the block)
     FtgpVehicle veh;              // host-side copy (the step kernel reads the LDS image VehLds; from here on nothing is staged into LDS)
     double wheel_load[4];
+    int32_t group_order[FTGP_MAX_GROUPS];      // the groups of a car (64 consecutive rays each) by expected march length, longest first: rays along the
+                                  // car's axis look down the track, sideways rays hit the corridor wall at once (read with scalar loads)
 };
 
 // vehicle constants as staged into LDS
@@ -159,7 +162,9 @@ __host__ __device__ __forceinline__ double u01(uint64_t h) { return (double)(h >
 
 // ---------------------------------------------------------------------------------------------
 // wave64 helpers
-__device__ __forceinline__ int lane_id() { return threadIdx.x & (FTGP_WAVE - 1); }
+// (from the hardware's lane counters, not from threadIdx.x: the thread index then need not be kept in a register -- or in scratch
+// memory -- for the whole life of a persistent kernel)
+__device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
 __device__ __forceinline__ double shfl_xor_f64(double v, int m)
 {

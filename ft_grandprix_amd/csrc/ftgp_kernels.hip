@@ -457,14 +457,14 @@ __device__ __forceinline__ void lidar_pool(const DeviceParams& P, ScalarParams G
 // instruction (profiles/round4/salu_cost.log) -- and the compiler's loop spends 13 scalar-side instructions per iteration on mask
 // bookkeeping.  Here a lane leaves the loop by dropping out of exec (v_cmpx on "the cell's entry is a box", i.e. kx != 0), so the
 // body needs no live mask, finished rays hold their cell and crossing time for free (and burn no vector lanes), and the loop
-// closes with one branch on exec: 21 vector + 4 scalar-side instructions per iteration, + the near-boundary path.
+// closes with one branch on exec: 20 vector + 4 scalar-side instructions per iteration, + the near-boundary path.
 // In: exec = the lanes that hold a ray; ix, iy = (mirrored) cell, s = crossing time into it (0 at the origin).
 // Out: w = entry of the terminal cell (0 = wall, FTGP_FIELD_OUT = ring), s = crossing time into it, exec as on entry.
 // The arithmetic is ftgp_ray_step / ftgp_ray_fix / ftgp_ray_commit of ftgp_march.h, instruction for instruction.
 __device__ __forceinline__ void march_all(int& ix, int& iy, float& s, uint32_t& w, float pum, float pvm, float ivx, float ivy, float dum, float dvm,
                                           int offC, int ax, int ay, float thr /* 0.5f - eps */, const void* field)
 {
-    int a, b, c, d, e, f, g, h, i;
+    int a, b, c, d, e, f, h, i;
     uint64_t stepx, sv, sq, ex0;
     asm volatile(
         "s_mov_b64 %[ex0], exec\n"
@@ -486,7 +486,7 @@ __device__ __forceinline__ void march_all(int& ix, int& iy, float& s, uint32_t& 
         "v_cmp_lt_f32_e64 %[stepx], %[a], %[b]\n\t"                      // the x edge of the box is reached first (a tie steps in y)
         "v_fma_f32 %[e], %[dvm], %[a], %[pvm]\n\t"                       // landing estimate after an x-jump ...
         "v_fma_f32 %[f], %[dum], %[b], %[pum]\n\t"                       // ... after a y-jump
-        "v_cndmask_b32_e64 %[g], %[b], %[a], %[stepx]\n\t"               // sn
+        "v_cndmask_b32_e64 %[s], %[b], %[a], %[stepx]\n\t"               // s = sn (a lane that ended on this lookup left exec above and keeps its s)
         "v_cndmask_b32_e64 %[e], %[f], %[e], %[stepx]\n\t"               // v
         "v_cvt_flr_i32_f32_e32 %[h], %[e]\n\t"                           // t = floor(v)
         "v_fract_f32_e32 %[f], %[e]\n\t"
@@ -496,7 +496,6 @@ __device__ __forceinline__ void march_all(int& ix, int& iy, float& s, uint32_t& 
         "L_march_commit_%=:\n\t"
         "v_cndmask_b32_e64 %[ix], %[h], %[c], %[stepx]\n\t"
         "v_cndmask_b32_e64 %[iy], %[d], %[h], %[stepx]\n\t"
-        "v_mov_b32_e32 %[s], %[g]\n\t"
         "s_branch L_march_loop_%=\n"
         "L_march_fix_%=:\n\t"                                            // ftgp_ray_fix() for the lanes in vcc
         "s_and_saveexec_b64 %[sv], vcc\n\t"
@@ -509,8 +508,8 @@ __device__ __forceinline__ void march_all(int& ix, int& iy, float& s, uint32_t& 
         "v_sub_f32_e32 %[a], %[e], %[a]\n\t"
         "v_mul_f32_e32 %[a], %[b], %[a]\n\t"                             // its crossing time, the specification's way
         "v_cvt_i32_f32_e32 %[b], %[e]\n\t"
-        "v_cmp_lt_f32_e64 vcc, %[a], %[g]\n\t"
-        "v_cmp_le_f32_e64 %[sq], %[a], %[g]\n\t"
+        "v_cmp_lt_f32_e64 vcc, %[a], %[s]\n\t"
+        "v_cmp_le_f32_e64 %[sq], %[a], %[s]\n\t"
         "s_and_b64 %[sq], %[sq], %[stepx]\n\t"                           // crossed: S <= sn after an x-jump, S < sn after a y-jump
         "s_or_b64 vcc, vcc, %[sq]\n\t"
         "v_cndmask_b32_e64 %[a], -1, 0, vcc\n\t"
@@ -521,7 +520,7 @@ __device__ __forceinline__ void march_all(int& ix, int& iy, float& s, uint32_t& 
         "L_march_done_%=:\n\t"
         "s_mov_b64 exec, %[ex0]"
         : [ix] "+v"(ix), [iy] "+v"(iy), [s] "+v"(s), [w] "+v"(w),
-          [a] "=&v"(a), [b] "=&v"(b), [c] "=&v"(c), [d] "=&v"(d), [e] "=&v"(e), [f] "=&v"(f), [g] "=&v"(g), [h] "=&v"(h), [i] "=&v"(i),
+          [a] "=&v"(a), [b] "=&v"(b), [c] "=&v"(c), [d] "=&v"(d), [e] "=&v"(e), [f] "=&v"(f), [h] "=&v"(h), [i] "=&v"(i),
           [stepx] "=&s"(stepx), [sv] "=&s"(sv), [sq] "=&s"(sq), [ex0] "=&s"(ex0)
         : [pum] "v"(pum), [pvm] "v"(pvm), [ivx] "v"(ivx), [ivy] "v"(ivy), [dum] "v"(dum), [dvm] "v"(dvm),
           [offC] "v"(offC), [ax] "v"(ax), [ay] "v"(ay), [thr] "s"(thr), [field] "s"(field)
@@ -540,7 +539,7 @@ __device__ __forceinline__ void lidar_groups(const DeviceParams& P, ScalarParams
 {
     typedef __attribute__((address_space(1))) float* global_f32;
     typedef __attribute__((address_space(1))) unsigned char* global_u8w;
-    const int R = G->n_rays, gpc = G->groups_per_car, ngroups = ncars_here * gpc;
+    const int R = G->n_rays, cpb = G->cars_per_block, ngroups = cpb * G->groups_per_car;
     const int W = G->width, H = G->height, fstride = G->fstride, stride = G->ranges_stride;
     const uint32_t plane256 = G->plane256, gmagic = G->group_magic;
     const int eighth = G->eighth, win_floats = G->win_floats;
@@ -558,8 +557,11 @@ __device__ __forceinline__ void lidar_groups(const DeviceParams& P, ScalarParams
         if (lane == 0) g = atomicAdd(pool, 1);
         g = __builtin_amdgcn_readfirstlane(g);
         if (g >= ngroups) break;
-        const int c = gmagic ? (int)__umulhi((uint32_t)g, gmagic) : g, j0 = (g - c * gpc) * FTGP_WAVE;      // car slot, first ray (wave-uniform)
-        const int j = j0 + lane;
+        // Group g = the kidx-th most expensive group (rays along the car's axis march longest, see group_order) of car slot g % cpb: the
+        // long groups of every car go first, so that the waves of a workgroup end a sweep within a short group of each other.
+        const int kidx = gmagic ? (int)__umulhi((uint32_t)g, gmagic) : g, c = g - kidx * cpb;
+        const int j0 = G->group_order[kidx] * FTGP_WAVE;                                        // first ray (wave-uniform)
+        const int j = c < ncars_here ? j0 + lane : R;                                           // (a ragged last workgroup draws groups of cars it does not have)
         FtgpRay ray;
         uint32_t w = FTGP_FIELD_OUT;
         float dxw = 0.0f, dyw = 0.0f;
@@ -603,12 +605,12 @@ __device__ __forceinline__ void lidar_groups(const DeviceParams& P, ScalarParams
                     }
                 }
             }
-            // the on-device drivers read ranges[0] and ranges[eighth : n - eighth]: that window is kept in LDS and goes to HBM as whole
-            // lines once the sweep is over (window_flush); everything else leaves now, 64 consecutive floats per wave
-            const int jw = j - eighth;
-            const bool in_window = scan_lds && (unsigned)jw < (unsigned)(R - 2 * eighth);
-            if (!in_window) *(global_f32)((global_u8w)(ranges + c * stride) + ((uint32_t)j << 2)) = r;
+            // every range leaves for HBM now, 64 consecutive floats per wave (one 256-byte row segment); the window the on-device drivers
+            // read next step -- ranges[0] and ranges[eighth : n - eighth] -- is kept in LDS as well
+            *(global_f32)((global_u8w)(ranges + c * stride) + ((uint32_t)j << 2)) = r;
             if (scan_lds) {
+                const int jw = j - eighth;
+                const bool in_window = (unsigned)jw < (unsigned)(R - 2 * eighth);
                 float* row = scan_rows + c * win_floats;
                 if (in_window) row[(eighth & 3) + jw] = r;
                 if (j0 == 0 && lane == 0) row[win_floats - 1] = r;
@@ -663,8 +665,8 @@ __device__ __forceinline__ void lidar_fake(ScalarParams G, const LidarFrame* fra
         }
         const float r = bad ? -1.0f : (float)((distance / (double)W) * s);
         const int jw = j - eighth;
-        const bool in_window = scan_lds && (unsigned)jw < (unsigned)(R - 2 * eighth);
-        if (!in_window) ranges[(size_t)c * stride + j] = r;
+        const bool in_window = (unsigned)jw < (unsigned)(R - 2 * eighth);
+        ranges[(size_t)c * stride + j] = r;
         if (scan_lds) {
             float* row = scan_rows + c * win_floats;
             if (in_window) row[(eighth & 3) + jw] = r;
@@ -857,7 +859,8 @@ __device__ __forceinline__ Force wall_term(const DeviceParams& P, const FtgpVehi
         const double rxw = softener ? ch * v.wheel_x[k] - sh * v.wheel_y[k] : ch * v.contact_x[k];
         const double ryw = softener ? sh * v.wheel_x[k] + ch * v.wheel_y[k] : sh * v.contact_x[k];
         px = st->x + rxw; py = st->y + ryw;
-        h = wall_search(P, P.bits, P.nearbits, px, py, softener ? v.softener_radius : v.contact_radius);
+        // (the two bitmap pointers are wave-uniform: in scalar registers they do not count against the 64 vector registers)
+        h = wall_search(P, uniform_ptr(P.bits), uniform_ptr(P.nearbits), px, py, softener ? v.softener_radius : v.contact_radius);
     }
     FTGP_FORGET_REGISTERS();
     Force t = { 0.0, 0.0, 0.0 };
@@ -1351,11 +1354,11 @@ __device__ __forceinline__ double wave_sum_f64(double v)
 
 // called by ALL threads of the workgroup, after the state records have gone back to HBM; `scratch`: one int of LDS
 __device__ __forceinline__ void launch_metrics(const DeviceParams& P, const CarCore* cars_lds, const int64_t* steps_lds, int ncars_here, int ci0,
-                                               unsigned char* scratch, int slot)
+                                               unsigned char* scratch, int slot, int wave)
 {
     int* last_flag = reinterpret_cast<int*>(scratch);
     const int lane = lane_id();
-    if (threadIdx.x < FTGP_WAVE) {                       // wave 0: one car per lane (a workgroup holds at most 16)
+    if (wave == 0) {                       // wave 0: one car per lane (a workgroup holds at most 16)
         double v[7] = { 0, 0, 0, 0, 0, INFINITY, -INFINITY };      // steps, laps, absolute completion, finished, off track, min / max lap time
         if (lane < ncars_here) {
             const CarCore* a = cars_lds + lane;
@@ -1384,12 +1387,12 @@ __device__ __forceinline__ void launch_metrics(const DeviceParams& P, const CarC
     }
     __syncthreads();
     if (!*last_flag) return;                              // workgroup-uniform
-    if (threadIdx.x == 0) {
+    if (wave == 0 && lane == 0) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
-    if (threadIdx.x < FTGP_WAVE) {
+    if (wave == 0) {
         double v[FTGP_METRIC_DOUBLES] = { 0, 0, 0, 0, 0, 0, INFINITY, -INFINITY };
         for (unsigned int b = lane; b < gridDim.x; b += FTGP_WAVE) {
             const double* r = P.wg_metrics + (size_t)b * FTGP_METRIC_DOUBLES;
@@ -1518,7 +1521,9 @@ __global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(cons
             __builtin_amdgcn_s_setprio(3);
 #endif
             for (int c = wave; c < ncars_here; c += nwaves) {
-                if (need_scan && it > 0) window_flush(G, scan_prev + c * win_floats, ci0 + c);     // the previous sweep's window, before the driver edits it
+#ifdef FTGP_SWEEP_V1
+                if (!FAKE && need_scan && it > 0) window_flush(G, scan_prev + c * win_floats, ci0 + c);     // the previous sweep's window, before the driver edits it
+#endif
                 if (policy != FTGP_POLICY_HOST) policy_apply(P, driver_shape(G), policy, scan_prev + c * win_floats, L.cars + c, ci0 + c, L.steps[c], L.list + wave * FTGP_WAVE, L.cover);
                 wave_lds_sync();
                 // "my controls are in LDS" -> the wave that counts last reads every car's controls: release on this side (the
@@ -1569,15 +1574,17 @@ __global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(cons
     const Lds L = lds_view(off_end, lds);
     for (int c = wave; c < ncars_here; c += nwaves) {
         const int ci = ci0 + c;
-        if (need_scan && n_steps > 0)          // the last sweep's window
+#ifdef FTGP_SWEEP_V1
+        if (!FAKE && need_scan && n_steps > 0)          // the last sweep's window
             window_flush(&P, L.scan + (((n_steps - 1) & 1) * cpb + c) * P.win_floats, ci);
+#endif
         if (lane < (int)(sizeof(CarCore) / 4))
             reinterpret_cast<uint32_t*>(static_cast<CarCore*>(&P.cars[ci]))[lane] = reinterpret_cast<const uint32_t*>(L.cars + c)[lane];
         if (lane == 0 && ci % P.cars_per_env == 0) P.steps[ci / P.cars_per_env] = L.steps[c];
     }
     if (P.wg_metrics) {                  // the scan windows are dead now: their first bytes serve as the reduction scratch
         __syncthreads();
-        launch_metrics(P, L.cars, L.steps, ncars_here, ci0, lds + P.off_scan, metrics_slot);
+        launch_metrics(P, L.cars, L.steps, ncars_here, ci0, lds + P.off_scan, metrics_slot, wave);
     }
 #ifdef FTGP_WG_TIMES
     __syncthreads();

@@ -42,7 +42,7 @@ FTGP_HD float ftgp_float(uint32_t b) { float x; memcpy(&x, &b, 4); return x; }
 #endif
 
 #define FTGP_SLOPE_SLICES (FTGP_SECTORS / 8)
-static_assert(FTGP_SECTORS == 8 || FTGP_SECTORS == 16 || FTGP_SECTORS == 32 || FTGP_SECTORS == 64, "8, 16, 32 or 64 sectors");
+static_assert(FTGP_SECTORS == 8 || FTGP_SECTORS == 16 || FTGP_SECTORS == 32 || FTGP_SECTORS == 64 || FTGP_SECTORS == 128, "8, 16, 32, 64 or 128 sectors");
 
 // Entry of pixel (x, y) for sector = (mirror x) | (mirror y) << 1 | (y-dominant) << 2 | (slope slice) << 3.
 //   runx[d][y][x] wall-free run length starting at the pixel along +x (d = 0) / -x (d = 1); runy likewise
@@ -94,15 +94,16 @@ FTGP_HD uint32_t ftgp_box_entry(const uint16_t* runx, const uint16_t* runy, int 
 FTGP_HD uint32_t ftgp_plane256(int W, int H) { return (2u * (uint32_t)(W + 2) * (uint32_t)(H + 2) + 255u) >> 8; }
 
 // Distance to a pixel boundary below which the landing estimate floor(p + d * s) is not trusted and the specification's
-// comparisons decide.  With unit roundoff u = 2^-24 the estimate fl(p + d * s) is off by at most u * M and the specification's
-// crossing time ((float)b - p) * (1 / d) by a relative 3u, i.e. by at most 3u * M pixels (M = largest coordinate); twice that
-// bound, on the next power of two of M:  eps = 2 * 4u * M = 2^-21 * pow2ceil(max(W, H) + 2).
-// (The factor 2 is a safety margin on top of a rigorous bound: the power of two above M already leaves 1.0 .. 2.0 x.)
+// comparison decides.  With unit roundoff u = 2^-24: the estimate fl(p + d * s) is off by at most u * M from p + d * s (one
+// rounding; M = largest coordinate), and the specification's own decision -- sY(k) <= s with sY(k) = fl(fl(k - p) * fl(1 / d)), three
+// roundings -- flips at a point that is off by at most 3u * M from where p + d * s crosses k; both use the same binary32 s.  So the
+// two can only disagree within 4u * M of a boundary:  eps = 4u * pow2ceil(max(W, H) + 2) = 2^-22 * pow2ceil(...), 2^-11 px for a
+// 1600-px track (the power of two above M leaves another 1.0 .. 2.0 x; rounds 1-3 shipped twice this value).
 FTGP_HD float ftgp_snap_eps(int W, int H)
 {
     const int m = (W > H ? W : H) + 2;
     int p = 1; while (p < m) p <<= 1;
-    return (float)p * (1.0f / 2097152.0f);
+    return (float)p * (1.0f / 4194304.0f);
 }
 
 // One ray in the mirrored frame.  A mirrored coordinate is the complement of the true one (ix = ~x = -x - 1), so the byte offset of

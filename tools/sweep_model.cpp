@@ -122,6 +122,38 @@ int main(int argc, char** argv)
     }
     const int iso_mode = getenv("ISO") ? atoi(getenv("ISO")) : 0;
     long iso_used = 0, iso_near = 0;
+    if (getenv("HIST")) {          // iterations per ray, and per group of 64 consecutive rays (= the slowest ray of the group): lidar_groups
+        std::vector<long> hr(64, 0), hg(64, 0); long sum_g = 0, ng = 0, sum_r = 0;
+        std::vector<long> by_index(R, 0);
+        for (int c = 0; c < n_cars; ++c) {
+            const double* p = &pose[(size_t)c * 4];
+            const double ch = 1.0 - 2.0 * (p[3] * p[3]), sh = 2.0 * (p[2] * p[3]);
+            const double lcx = p[0] + (ch * -0.0525 - sh * 0.0), lcy = p[1] + (sh * -0.0525 + ch * 0.0);
+            const float u0 = (float)((lcx - ph[3]) * (1.0 / ph[1])), v0 = (float)((ph[4] - lcy) * (1.0 / ph[2]));
+            const float chf = (float)ch, shf = (float)sh;
+            int gmax = 0;
+            for (int j = 0; j < R; ++j) {
+                const float dxw = fmaf(chf, bx[j], -(shf * by[j])), dyw = fmaf(shf, bx[j], chf * by[j]);
+                const float du = dxw * isx, dv = -(dyw * isy);
+                FtgpRay r; ftgp_ray_init(r, fmaf(du, -r0, u0), fmaf(dv, -r0, v0), du, dv, fabsf(1.0f / du), fabsf(1.0f / dv), W, H, fstride, plane256);
+                int n = 1;
+                for (; n < 100000; ++n) {
+                    const uint32_t wq = field[ftgp_ray_offset(r) >> 1];
+                    FtgpStep st; const bool near = ftgp_ray_step(r, wq, eps, st);
+                    ftgp_ray_commit(r, st, near ? ftgp_ray_fix(r, st) : st.t);
+                    if (!st.live) break;
+                }
+                hr[std::min(n, 63)]++; sum_r += n; by_index[j] += n;
+                gmax = std::max(gmax, n);
+                if ((j & 63) == 63 || j == R - 1) { hg[std::min(gmax, 63)]++; sum_g += gmax; ++ng; gmax = 0; }
+            }
+        }
+        printf("iterations per ray: mean %.2f; per group of 64: mean %.2f (x %.1f groups per car = %.1f wave-iterations per car-step)\n", (double)sum_r / ((double)n_cars * R), (double)sum_g / ng, (double)ng / n_cars, (double)sum_g / n_cars);
+        printf("  n    rays%%  groups%%\n");
+        for (int n = 1; n < 64; ++n) if (hr[n] || hg[n]) printf("%3d  %6.2f  %6.2f\n", n, 100.0 * hr[n] / ((double)n_cars * R), 100.0 * hg[n] / ng);
+        printf("mean iterations by ray index (every 30th):"); for (int j = 0; j < R; j += 30) printf(" %d:%.1f", j, (double)by_index[j] / n_cars); printf("\n");
+        return 0;
+    }
     struct Lane { FtgpRay r; int g; bool done; };
     for (int c0 = 0; c0 < n_cars; c0 += cpb) {
         const int nc = std::min(cpb, n_cars - c0), total = nc * R;
