@@ -2,6 +2,7 @@
 // Host code only owns resources and launches; there is no CPU compute path (no fallback).
 #include <dlfcn.h>
 #include <math.h>
+#include <cmath>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -446,8 +447,7 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
     { hipDeviceProp_t prop; CREATE_TRY(hipGetDeviceProperties(&prop, e->device)); P.n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256; }
     P.edge_margin = (float)(v.lidar_ring_radius * std::max(P.inv_px_x, P.inv_px_y) * 1.001 + 2.0);
     P.ray_magic = (uint32_t)((0x100000000ull + (uint64_t)cfg->n_rays - 1) / (uint64_t)cfg->n_rays);
-    P.groups_per_car = (cfg->n_rays + FTGP_WAVE - 1) / FTGP_WAVE;
-    if (P.groups_per_car > FTGP_MAX_GROUPS) { ftgp_destroy(e); return fail(FTGP_ERR_ARG, "n_rays above 16384 is not supported%s"); }
+    if ((cfg->n_rays + FTGP_WAVE - 1) / FTGP_WAVE > FTGP_MAX_GROUPS) { ftgp_destroy(e); return fail(FTGP_ERR_ARG, "n_rays above 16384 is not supported%s"); }
 
     // workgroup shape: whole envs, at most 16 cars (K1 / K3 run on the lanes of one wave), two workgroups per CU
     // (<= 80 KiB of LDS each) so that 8 waves per SIMD hide the latency of the field loads
@@ -479,21 +479,6 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
                 return FTGP_ERR_ARG;
             }
     }
-    {   // the sweep's work list: group draw g -> (kidx = g / cars_per_block, car slot = g % cars_per_block), group = group_order[kidx]
-        const uint32_t cpbu = (uint32_t)P.cars_per_block;
-        P.group_magic = cpbu == 1 ? 0u : (uint32_t)((0x100000000ull + cpbu - 1) / cpbu);
-        for (uint32_t g = 0; P.group_magic && g < cpbu * (uint32_t)P.groups_per_car + 64; ++g)
-            if ((uint32_t)(((uint64_t)g * P.group_magic) >> 32) != g / cpbu) { ftgp_destroy(e); return fail(FTGP_ERR_ARG, "internal: group_magic is not exact%s"); }
-        // expected march length of a group ~ how far its rays look along the car's axis: |cos| of the angle between the group's middle ray
-        // and the axis (ray 0 looks backwards, ray n/2 ahead); ties keep index order
-        std::vector<std::pair<double, int>> key;
-        for (int k = 0; k < P.groups_per_car; ++k) {
-            const double mid = std::min((double)cfg->n_rays - 1.0, 64.0 * k + 31.5);
-            key.push_back({ -fabs(cos(2.0 * M_PI * mid / (double)cfg->n_rays)), k });
-        }
-        std::stable_sort(key.begin(), key.end());
-        for (int k = 0; k < P.groups_per_car; ++k) P.group_order[k] = getenv("FTGP_GROUP_ORDER_PLAIN") ? k : key[(size_t)k].second;
-    }
     CREATE_TRY(hipFuncSetAttribute((const void*)ftgp_step_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     CREATE_TRY(hipFuncSetAttribute((const void*)ftgp_step_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     CREATE_TRY(hipFuncSetAttribute((const void*)ftgp_step_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -509,7 +494,53 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
         const double phi = ((360.0 / (double)cfg->n_rays) * (double)j - 90.0) * (M_PI / 180.0);
         fan[2 * (size_t)j] = cfg->fan_dirs ? cfg->fan_dirs[2 * (size_t)j] : sin(phi);
         fan[2 * (size_t)j + 1] = cfg->fan_dirs ? cfg->fan_dirs[2 * (size_t)j + 1] : -cos(phi);
+        // The rangefinders' own fan is point-symmetric: site j + n/2 looks exactly opposite to site j.  The table says so to the last bit
+        // (the second half is the negated first half -- libm's sin / cos of phi + pi need not be), which is what lets the sweep derive a
+        // ray from its opposite; a caller's fan_dirs is taken as it comes.
+        if (!cfg->fan_dirs && cfg->n_rays % 2 == 0 && j >= cfg->n_rays / 2) {
+            fan[2 * (size_t)j] = -fan[2 * (size_t)(j - cfg->n_rays / 2)]; fan[2 * (size_t)j + 1] = -fan[2 * (size_t)(j - cfg->n_rays / 2) + 1];
+        }
         ray[2 * (size_t)j] = (float)fan[2 * (size_t)j]; ray[2 * (size_t)j + 1] = (float)fan[2 * (size_t)j + 1];
+    }
+    {   // the sweep's work list (lidar_groups): draw g -> (kidx = g / cars_per_block, car slot = g % cars_per_block), task = group_order[kidx]
+        const int R = cfg->n_rays, halfR = R / 2;
+        bool sym = R % 2 == 0 && !getenv("FTGP_NO_PAIRS");
+        for (int j = 0; sym && j < halfR; ++j)
+            sym = ray[2 * (size_t)(j + halfR)] == -ray[2 * (size_t)j] && ray[2 * (size_t)(j + halfR) + 1] == -ray[2 * (size_t)j + 1] &&
+                  std::signbit(ray[2 * (size_t)(j + halfR)]) != std::signbit(ray[2 * (size_t)j]) && std::signbit(ray[2 * (size_t)(j + halfR) + 1]) != std::signbit(ray[2 * (size_t)j + 1]);
+        std::vector<int> tasks;
+        if (!sym) for (int j0 = 0; j0 < R; j0 += FTGP_WAVE) tasks.push_back(j0);
+        else {
+            int j0 = 0;
+            for (; j0 + FTGP_WAVE <= halfR; j0 += FTGP_WAVE) tasks.push_back(j0 | (1 << 16));
+            if (j0 < halfR) tasks.push_back(j0 | ((halfR - j0 <= FTGP_WAVE / 2 ? 2 : 1) << 16));
+        }
+        P.tasks_per_car = (int)tasks.size();
+        const uint32_t cpbu = (uint32_t)P.cars_per_block;
+        P.group_magic = cpbu == 1 ? 0u : (uint32_t)((0x100000000ull + cpbu - 1) / cpbu);
+        for (uint32_t g = 0; P.group_magic && g < cpbu * (uint32_t)(2 * P.tasks_per_car + 4) + 64; ++g)
+            if ((uint32_t)(((uint64_t)g * P.group_magic) >> 32) != g / cpbu) { ftgp_destroy(e); return fail(FTGP_ERR_ARG, "internal: group_magic is not exact%s"); }
+        // expected march length of a task ~ how far its rays look along the car's axis: |cos| of the angle between the group's middle ray
+        // and the axis (ray 0 looks backwards, ray n/2 ahead); ties keep index order
+        std::vector<std::pair<double, int>> key;
+        for (int t : tasks) {
+            const double mid = std::min((double)R - 1.0, (double)(t & 0xffff) + 31.5);
+            key.push_back({ getenv("FTGP_GROUP_ORDER_PLAIN") ? 0.0 : -fabs(cos(2.0 * M_PI * mid / (double)R)), t });
+        }
+        std::stable_sort(key.begin(), key.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) { return a.first < b.first; });
+        // the cheapest pairs -- the last tasks a sweep draws -- go out as two single groups each: the waves then end a sweep within ONE short
+        // group of each other, not within two (the set-up shared inside a pair is worth less than that at the very end)
+        int tail = 2;
+        if (const char* sv = getenv("FTGP_PAIR_TAIL")) tail = atoi(sv);
+        std::vector<int> order;
+        for (size_t k = 0; k < key.size(); ++k) {
+            const int t = key[k].second;
+            if ((t >> 16) == 1 && (int)(key.size() - k) <= tail) { order.push_back(t & 0xffff); order.push_back((t & 0xffff) + halfR); }
+            else order.push_back(t);
+        }
+        P.tasks_per_car = (int)order.size();
+        for (size_t k = 0; k < order.size(); ++k) P.group_order[k] = order[k];
+        if (getenv("FTGP_VERBOSE")) fprintf(stderr, "ftgp_create: %d sweep tasks per car (%s)\n", P.tasks_per_car, sym ? "pairs of opposite ray groups" : "single groups");
     }
     std::vector<double> spawn(4 * FTGP_PATH_POINTS);
     for (int p = 0; p < FTGP_PATH_POINTS; ++p) {

@@ -78,7 +78,7 @@ struct DeviceParams {
     const double* fan_dirs;       // [n_rays][2] body-frame fan directions, binary64
     double map_size;              // 20 * scale = 40 (custom.py:1382)
     int32_t lidar_mode, pad_e;
-    int32_t groups_per_car;       // ceil(n_rays / 64): the sweep hands out groups of 64 consecutive rays of one car (lidar_groups)
+    int32_t tasks_per_car;        // the sweep's work list per car (lidar_groups): groups of 64 consecutive rays, or pairs of opposite groups
     uint32_t group_magic;         // ceil(2^32 / cars_per_block) (0 for one car per block): group draw -> (rank of the group, car slot) without a division
     const uint16_t* field;        // [FTGP_SECTORS][height + 2][width + 2] box entries (ftgp_march.h), HBM/L2
     const uint32_t* bits;         // [height][words_per_row] wall bitmap
@@ -102,8 +102,10 @@ struct DeviceParams {
     alignas(16) int32_t sector_tab[FTGP_SECTORS][4];     // ftgp_sector_entry() of every sector (staged into LDS with the head of the block)
     FtgpVehicle veh;              // host-side copy (the step kernel reads the LDS image VehLds; from here on nothing is staged into LDS)
     double wheel_load[4];
-    int32_t group_order[FTGP_MAX_GROUPS];      // the groups of a car (64 consecutive rays each) by expected march length, longest first: rays along the
-                                  // car's axis look down the track, sideways rays hit the corridor wall at once (read with scalar loads)
+    int32_t group_order[FTGP_MAX_GROUPS];      // the tasks of a car by expected march length, longest first (rays along the car's axis look down the
+                                  // track, sideways rays hit the corridor wall at once): first ray | kind << 16, kind 0 = one group of 64
+                                  // consecutive rays, 1 = that group and the opposite one (first ray + n/2), 2 = the short ends of both halves in
+                                  // one group (lanes 0..31 / 32..63); read with scalar loads
 };
 
 // vehicle constants as staged into LDS

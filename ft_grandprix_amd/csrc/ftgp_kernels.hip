@@ -527,19 +527,23 @@ __device__ __forceinline__ void march_all(int& ix, int& iy, float& s, uint32_t& 
         : "vcc", "scc", "memory");
 }
 
-// The sweep of one step for all cars of the workgroup, by every wave, in GROUPS of 64 consecutive rays of one car: a wave takes the
-// next group (one LDS atomic), sets its 64 rays up, marches them until all have finished (march_all), stores the 64 ranges, and takes
-// the next group.  Nothing is handed out ray by ray: no ranks, no per-lane bookkeeping, no partial refills -- the price is that a
-// group lasts as long as its slowest ray (lane utilisation 0.61 against 0.78 with batched refills, tools/sweep_model.cpp), paid in
-// lanes that sit masked out, not in instructions: a set-up costs about 60 instructions per 64 rays against 150 per 52, an
-// iteration 25 against 35.  Rays of a group are neighbours: they share field lines, and their ranges leave as one row segment.
+// The sweep of one step for all cars of the workgroup, by every wave, in GROUPS of 64 consecutive rays of one car: a wave draws the
+// next task (one LDS atomic), sets its 64 rays up, marches them until all have finished (march_all), stores the 64 ranges, and draws
+// again.  Nothing is handed out ray by ray: no ranks, no per-lane bookkeeping, no partial refills -- the price is that a group
+// lasts as long as its slowest ray (lane utilisation 0.61 against 0.78 with batched refills, tools/sweep_model.cpp), paid in lanes
+// that sit masked out, not in instructions: a set-up costs about 60 instructions per 64 rays against 150 per 52, an iteration 24
+// against 35.  Rays of a group are neighbours: they share field lines, and their ranges leave as one 256-byte row segment.
+// With the rangefinders' own fan -- ray j + n/2 points exactly opposite to ray j (ftgp_create builds the table that way) -- a task is
+// a PAIR of groups, j0 .. j0 + 63 and the same rays turned round: the second group keeps the first one's |direction|, reciprocals and
+// slope slice (the two divisions and the sector search are half of a set-up) and only places its rays anew (ftgp_ray_place with
+// sector ^ 3).  Tasks are drawn long-first across the workgroup's cars (group_order), so that the waves end a sweep together.
 template <bool MULTI>
 __device__ __forceinline__ void lidar_groups(const DeviceParams& P, ScalarParams G, const Lds& L, const LidarFrame* frames, const PairCull* pairs, float* scan_rows, int* pool,
                                              int ncars_here, int ci0, bool scan_lds, bool second_half STAMP_ARG)
 {
     typedef __attribute__((address_space(1))) float* global_f32;
     typedef __attribute__((address_space(1))) unsigned char* global_u8w;
-    const int R = G->n_rays, cpb = G->cars_per_block, ngroups = cpb * G->groups_per_car;
+    const int R = G->n_rays, half = R >> 1, cpb = G->cars_per_block, ntasks = cpb * G->tasks_per_car;
     const int W = G->width, H = G->height, fstride = G->fstride, stride = G->ranges_stride;
     const uint32_t plane256 = G->plane256, gmagic = G->group_magic;
     const int eighth = G->eighth, win_floats = G->win_floats;
@@ -556,39 +560,27 @@ __device__ __forceinline__ void lidar_groups(const DeviceParams& P, ScalarParams
         int g = 0;
         if (lane == 0) g = atomicAdd(pool, 1);
         g = __builtin_amdgcn_readfirstlane(g);
-        if (g >= ngroups) break;
-        // Group g = the kidx-th most expensive group (rays along the car's axis march longest, see group_order) of car slot g % cpb: the
-        // long groups of every car go first, so that the waves of a workgroup end a sweep within a short group of each other.
+        if (g >= ntasks) break;
+        // Draw g = the kidx-th most expensive task (rays along the car's axis march longest, see group_order) of car slot g % cpb: the
+        // long tasks of every car go first, so that the waves of a workgroup end a sweep within a short group of each other.
         const int kidx = gmagic ? (int)__umulhi((uint32_t)g, gmagic) : g, c = g - kidx * cpb;
-        const int j0 = G->group_order[kidx] * FTGP_WAVE;                                        // first ray (wave-uniform)
-        const int j = c < ncars_here ? j0 + lane : R;                                           // (a ragged last workgroup draws groups of cars it does not have)
+        const int ent = G->group_order[kidx];                     // first ray | kind << 16 (wave-uniform)
+        const int j0 = ent & 0xffff, kind = ent >> 16;            // kind 0: one group; 1: a group and its opposite; 2: both halves in one group
+        int j; bool mine;
+        if (kind == 2) { j = j0 + (lane & 31) + (lane >= 32 ? half : 0); mine = (lane & 31) < half - j0; }
+        else { j = j0 + lane; mine = j < (kind == 1 ? half : R); }
+        mine = mine && c < ncars_here;               // (a ragged last workgroup draws tasks of cars it does not have)
         FtgpRay ray;
-        uint32_t w = FTGP_FIELD_OUT;
-        float dxw = 0.0f, dyw = 0.0f;
-        const bool mine = j < R;                     // the last group of a car is short
-        if (mine) {
-            const float4 f4 = *reinterpret_cast<const float4*>(frames + c);      // u0, v0, chf, shf (one address for the wave)
-            const float2 bd = L.ray[j];
-            dxw = fmaf(f4.z, bd.x, -(f4.w * bd.y));
-            dyw = fmaf(f4.w, bd.x, f4.z * bd.y);
-            const float du = dxw * isx;
-            const float dv = -(dyw * isy);
-            const float pu = fmaf(du, -r0, f4.x);
-            const float pv = fmaf(dv, -r0, f4.y);
-            float ivx, ivy;
-            rcp_abs2(du, dv, ivx, ivy);
-            ray.result = -1.0f;
-            ftgp_ray_init(ray, pu, pv, du, dv, ivx, ivy, W, H, fstride, plane256, true, &P.sector_tab[0][0]);
-            if (!all_safe) {             // wave-uniform, rare: some car of the workgroup is near the image edge, off it, or has finished
-                ftgp_ray_park_if_outside(ray, pu, pv, W, H);
-                // a finished car's rangefinders are switched off (custom.py:1436-1439): its frame carries u0 = -inf, so the ray is
-                // parked like any ray that starts off the image, and reads 0 instead of -1
-                ray.result = (f4.x == -INFINITY) ? 0.0f : -1.0f;
-            }
-            STAMP(tb); STAMP_ADD(8, tb - ta); STAMP_ADD(9, 1);
+        float du = 0.0f, dv = 0.0f, dxw = 0.0f, dyw = 0.0f;
+        uint32_t sector = 0;
+        // march the lanes' rays and deliver their ranges: ftgp_ray_range(), the inter-vehicle test, the stores
+        auto finish = [&](bool active) {
+            if (!active) return;
+            uint32_t w = FTGP_FIELD_OUT;
+            STAMP(tb);
             march_all(ray.ix, ray.iy, ray.s, w, ray.pum, ray.pvm, ray.ivx, ray.ivy, ray.dum, ray.dvm, ray.offC, ray.ax, ray.ay, thr, field);
-            STAMP(tc); STAMP_ADD(10, tc - tb);
-            float r = (w == 0u) ? fabsf(ray.s) : ray.result;        // ftgp_ray_range()
+            STAMP(tc); STAMP_ADD(10, tc - tb); STAMP_ADD(9, 1);
+            float r = (w == 0u) ? fabsf(ray.s) : ray.result;
             if (MULTI) {
                 // Rays also see the other cars of the env (a9).  One record per env-mate (PairCull, written with the frames) rules a
                 // mate out with a dot product: it can only be touched if it lies in front of the ray and within `cull` of its line.
@@ -613,8 +605,46 @@ __device__ __forceinline__ void lidar_groups(const DeviceParams& P, ScalarParams
                 const bool in_window = (unsigned)jw < (unsigned)(R - 2 * eighth);
                 float* row = scan_rows + c * win_floats;
                 if (in_window) row[(eighth & 3) + jw] = r;
-                if (j0 == 0 && lane == 0) row[win_floats - 1] = r;
+                if (j == 0) row[win_floats - 1] = r;
             }
+        };
+        if (mine) {
+            const float4 f4 = *reinterpret_cast<const float4*>(frames + c);      // u0, v0, chf, shf (one address for the wave)
+            const float2 bd = L.ray[j];
+            dxw = fmaf(f4.z, bd.x, -(f4.w * bd.y));
+            dyw = fmaf(f4.w, bd.x, f4.z * bd.y);
+            du = dxw * isx;
+            dv = -(dyw * isy);
+            const float pu = fmaf(du, -r0, f4.x);
+            const float pv = fmaf(dv, -r0, f4.y);
+            float ivx, ivy;
+            rcp_abs2(du, dv, ivx, ivy);
+            ray.result = -1.0f;
+            sector = ftgp_ray_sector(du, dv, ivx, ivy);
+            ftgp_ray_place(ray, pu, pv, du, dv, ivx, ivy, sector, W, H, fstride, plane256, true, &P.sector_tab[0][0]);
+            if (!all_safe) {             // wave-uniform, rare: some car of the workgroup is near the image edge, off it, or has finished
+                ftgp_ray_park_if_outside(ray, pu, pv, W, H);
+                // a finished car's rangefinders are switched off (custom.py:1436-1439): its frame carries u0 = -inf, so the ray is
+                // parked like any ray that starts off the image, and reads 0 instead of -1
+                ray.result = (f4.x == -INFINITY) ? 0.0f : -1.0f;
+            }
+        }
+        STAMP(td); STAMP_ADD(8, td - ta);
+        finish(mine);
+        if (kind == 1) {                 // the same rays turned round: ray j + n/2 = -(ray j), exactly
+            if (mine) {
+                j += half;
+                const float4 f4 = *reinterpret_cast<const float4*>(frames + c);
+                du = -du; dv = -dv; dxw = -dxw; dyw = -dyw;
+                const float pu = fmaf(du, -r0, f4.x);
+                const float pv = fmaf(dv, -r0, f4.y);
+                ftgp_ray_place(ray, pu, pv, du, dv, ray.ivx, ray.ivy, sector ^ 3u, W, H, fstride, plane256, true, &P.sector_tab[0][0]);
+                if (!all_safe) {
+                    ftgp_ray_park_if_outside(ray, pu, pv, W, H);
+                    ray.result = (f4.x == -INFINITY) ? 0.0f : -1.0f;
+                }
+            }
+            finish(mine);
         }
     }
 }

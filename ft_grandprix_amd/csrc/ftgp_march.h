@@ -139,34 +139,17 @@ FTGP_HD void ftgp_sector_entry(int32_t* e, uint32_t sector, int fstride, uint32_
     e[1] = 2 + 4 * mxm; e[2] = hy + hy; e[3] = 0;
 }
 
-FTGP_HD void ftgp_ray_init(FtgpRay& r, float pu, float pv, float du, float dv, float ivx, float ivy, int W, int H, int fstride, uint32_t plane256,
-                           bool assume_inside = false, const int32_t* sector_tab = nullptr)
+// Sector of a direction: (mirror x) | (mirror y) << 1 | (y-dominant) << 2 | (slope slice) << 3.  Mirrors and dominant axis come out of
+// sign bits and one compare; the OPPOSITE direction (-du, -dv) has exactly this sector with the two mirror bits flipped (sector ^ 3).
+FTGP_HD uint32_t ftgp_ray_sector(float du, float dv, float ivx, float ivy)
 {
-#if defined(__HIP_DEVICE_COMPILE__)
-    int ix0, iy0;                                             // floor and convert in one instruction; the conversion saturates
-    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ix0) : "v"(pu));
-    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(iy0) : "v"(pv));
-    const bool inside = assume_inside || (!__builtin_isunordered(pu, pv) && (unsigned)ix0 < (unsigned)W && (unsigned)iy0 < (unsigned)H);   // a NaN converts to 0: test it
-#else
-    const float fx = floorf(pu), fy = floorf(pv);
-    const bool inside = assume_inside || (fx >= 0.0f && fx < (float)W && fy >= 0.0f && fy < (float)H);
-    const int ix0 = (int)fx, iy0 = (int)fy;
-#endif
-    // Mirrors, slope slice and offsets come out of sign bits with adds, shifts and logic (2-cycle instructions on gfx950)
-    // rather than compares and selects (4 each).  A direction component of -0 mirrors its axis too: harmless, the ray never
-    // steps along it.  (The dominant axis stays a compare and two selects: fminf / fmaxf bring canonicalising v_max x, x, x
-    // along, and integer min / max on the bit patterns cost what the selects cost.)
+    // A direction component of -0 mirrors its axis too: harmless, the ray never steps along it.  (The dominant axis stays a compare
+    // and two selects: fminf / fmaxf bring canonicalising v_max x, x, x along, and integer min / max on the bit patterns cost what the
+    // selects cost.)
     const uint32_t bu = ftgp_bits(du), bv = ftgp_bits(dv);
-    const int mxm = (int)bu >> 31, mym = (int)bv >> 31;       // 0 / -1
     const float adu = fabsf(du), adv = fabsf(dv);
     const bool ydom = !(adu >= adv);
-    r.pum = ftgp_float(ftgp_bits(pu) ^ (bu & 0x80000000u));   // mirrored ? -p : p
-    r.pvm = ftgp_float(ftgp_bits(pv) ^ (bv & 0x80000000u));
-    r.dum = adu; r.dvm = adv;
-    r.ivx = ivx; r.ivy = ivy;
-    r.s = 0.0f;
-    if (!assume_inside) r.result = -1.0f;
-    uint32_t sector = ((uint32_t)mxm & 1u) | ((uint32_t)mym & 2u) | (ydom ? 4u : 0u);
+    uint32_t sector = (bu >> 31) | ((bv >> 31) << 1) | (ydom ? 4u : 0u);
     if (FTGP_SLOPE_SLICES > 1) {
         // slope slice = floor(NS * minor / major), with the reciprocal of the major component that is at hand anyway.  A few units
         // of rounding may put a ray that runs along a slice boundary into the neighbouring slice: harmless, the boxes of a
@@ -182,6 +165,32 @@ FTGP_HD void ftgp_ray_init(FtgpRay& r, float pu, float pv, float du, float dv, f
         // (a direction of (0, 0) or a NaN cannot occur: the components are a rotated unit vector, scaled)
         sector |= (uint32_t)slice << 3;
     }
+    return sector;
+}
+
+// Puts a ray of known sector on its start cell.  (ftgp_ray_init = ftgp_ray_sector + ftgp_ray_place; the step kernel places the ray
+// OPPOSITE to one it has just marched -- same |direction|, reciprocals and slope slice -- with sector ^ 3 and skips the first half.)
+FTGP_HD void ftgp_ray_place(FtgpRay& r, float pu, float pv, float du, float dv, float ivx, float ivy, uint32_t sector, int W, int H, int fstride, uint32_t plane256,
+                            bool assume_inside = false, const int32_t* sector_tab = nullptr)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    int ix0, iy0;                                             // floor and convert in one instruction; the conversion saturates
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(ix0) : "v"(pu));
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(iy0) : "v"(pv));
+    const bool inside = assume_inside || (!__builtin_isunordered(pu, pv) && (unsigned)ix0 < (unsigned)W && (unsigned)iy0 < (unsigned)H);   // a NaN converts to 0: test it
+#else
+    const float fx = floorf(pu), fy = floorf(pv);
+    const bool inside = assume_inside || (fx >= 0.0f && fx < (float)W && fy >= 0.0f && fy < (float)H);
+    const int ix0 = (int)fx, iy0 = (int)fy;
+#endif
+    const uint32_t bu = ftgp_bits(du), bv = ftgp_bits(dv);
+    const int mxm = (int)bu >> 31, mym = (int)bv >> 31;       // 0 / -1
+    r.pum = ftgp_float(ftgp_bits(pu) ^ (bu & 0x80000000u));   // mirrored ? -p : p
+    r.pvm = ftgp_float(ftgp_bits(pv) ^ (bv & 0x80000000u));
+    r.dum = fabsf(du); r.dvm = fabsf(dv);
+    r.ivx = ivx; r.ivy = ivy;
+    r.s = 0.0f;
+    if (!assume_inside) r.result = -1.0f;
     r.ix = ix0 ^ mxm; r.iy = iy0 ^ mym;
     if (sector_tab) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -205,6 +214,12 @@ FTGP_HD void ftgp_ray_init(FtgpRay& r, float pu, float pv, float du, float dv, f
 #endif
     r.offC = (int)(plane << 8) + (fstride + 2) + (mxm + mxm) + hy;
     if (!inside) { r.offC = 0; r.ax = r.ay = 0; }             // starts off the image: every cell maps to ring cell (0, 0) of plane 0, result stays -1
+}
+
+FTGP_HD void ftgp_ray_init(FtgpRay& r, float pu, float pv, float du, float dv, float ivx, float ivy, int W, int H, int fstride, uint32_t plane256,
+                           bool assume_inside = false, const int32_t* sector_tab = nullptr)
+{
+    ftgp_ray_place(r, pu, pv, du, dv, ivx, ivy, ftgp_ray_sector(du, dv, ivx, ivy), W, H, fstride, plane256, assume_inside, sector_tab);
 }
 
 // The on-image test of ftgp_ray_init for a caller that initialised with assume_inside although it could not promise it:

@@ -896,6 +896,8 @@ int oracle_create(const FtgpConfig *cfg, OracleEnv **out)
         double phi = ((360.0 / (double)R) * (double)j - 90.0) * (M_PI / 180.0);
         e->ray_bxd[j] = cfg->fan_dirs ? cfg->fan_dirs[2 * j] : sin(phi);
         e->ray_byd[j] = cfg->fan_dirs ? cfg->fan_dirs[2 * j + 1] : -cos(phi);
+        /* the rangefinders' own fan is point-symmetric, and the table is so to the last bit: site j + R/2 = -(site j) */
+        if (!cfg->fan_dirs && R % 2 == 0 && j >= R / 2) { e->ray_bxd[j] = -e->ray_bxd[j - R / 2]; e->ray_byd[j] = -e->ray_byd[j - R / 2]; }
         e->ray_bx[j] = (float)e->ray_bxd[j]; e->ray_by[j] = (float)e->ray_byd[j];
     }
     for (int p = 0; p < NPATH; ++p) {

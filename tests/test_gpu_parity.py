@@ -412,6 +412,35 @@ def test_headline_size_properties_and_oracle_prefix(product, oracle):
         assert g.last_kernel_ms() > 0
 
 
+@pytest.mark.parametrize("R,cars", [(1080, 1), (90, 3), (200, 1), (130, 2)])
+def test_custom_fan_takes_the_unpaired_sweep(product, oracle, R, cars):
+    """FtgpConfig.fan_dirs: a caller's fan is not point-symmetric to the bit, so the sweep cannot derive a ray from its opposite and
+    marches every group on its own (the rangefinders' own table is built symmetric and takes the paired path: every other test).
+    Both against the oracle, closed loop; with the default fan the two paths must agree with each other as well (FTGP_NO_PAIRS)."""
+    import os
+    t = load_track("track")
+    ang = np.deg2rad(360.0 / R * np.arange(R) - 90.0 + 0.37)               # the MJCF's sites turned by 0.37 degrees ...
+    ang[R // 2:] += 3e-5                                                   # ... and the second half a little further: no ray has an exact opposite
+    fan = np.stack([np.sin(ang), -np.cos(ang)], axis=1)
+    assert not np.array_equal(fan[R // 2:].astype(np.float32), -fan[: R - R // 2].astype(np.float32))
+    kw = dict(n_envs=12, cars_per_env=cars, n_rays=R, spawn_mode=1, seed=3)
+    with capi.Env(product, t, fan_dirs=fan, **kw) as g, capi.Env(oracle, t, fan_dirs=fan, **kw) as o:
+        for n in (1, 40, 300):
+            g.rollout("nidc", n); o.rollout("nidc", n)
+            np.testing.assert_array_equal(g.lidar(), o.lidar())
+            np.testing.assert_array_equal(g.progress(), o.progress())
+            np.testing.assert_allclose(g.pose(), o.pose(), rtol=0, atol=1e-12)
+    os.environ["FTGP_NO_PAIRS"] = "1"
+    try:
+        single = capi.Env(product, t, **kw)
+    finally:
+        del os.environ["FTGP_NO_PAIRS"]
+    with single, capi.Env(product, t, **kw) as paired:
+        single.rollout("fast", 250); paired.rollout("fast", 250)
+        np.testing.assert_array_equal(single.lidar(), paired.lidar())
+        np.testing.assert_array_equal(single.pose(), paired.pose())
+
+
 def test_gpu_shards_reproduce_the_monolithic_batch(product):
     """a shard [env_base, env_base + n) must equal the same slice of the whole batch (two handles, one GPU)."""
     from ft_grandprix_amd import dist as ftdist
