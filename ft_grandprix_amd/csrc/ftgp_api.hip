@@ -368,9 +368,14 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
     if (t.width < 1 || t.height < 1 || !t.bits || !t.path || t.words_per_row < (t.width + 31) / 32)
         return fail(FTGP_ERR_ARG, "bad track%s");
     if (t.width > 8192 || t.height > 8192) return fail(FTGP_ERR_ARG, "images above 8192 pixels are not supported%s");
-    // the march addresses the box field with a 32-bit byte offset (ftgp_ray_offset: plane << 8 + cell offsets)
-    if ((uint64_t)ftgp_plane256(t.width, t.height) * 256u * FTGP_SECTORS > 0xFFFFFFFFull)
-        return fail(FTGP_ERR_ARG, "track image too large: the sector box field (128 bytes per pixel) must stay below 4 GiB (about 33 million pixels)%s");
+    // Direction sectors of the box field: more slope slices mean fewer march iterations and a larger field.  A large batch is bound by
+    // throughput and by what of the field its cars keep in the 4-MiB L2s (16 sectors: 32 bytes per pixel); a small one by the latency of
+    // its longest rays (64 sectors).  Measured on both: profiles/round4/ab_sectors.log.  Results do not depend on the choice.
+    int n_sectors = (long)cfg->n_envs * cfg->cars_per_env >= 2048 ? 16 : 64;
+    if (const char* sv = getenv("FTGP_SECTORS_RT")) { const int c = atoi(sv); if (c == 8 || c == 16 || c == 32 || c == 64) n_sectors = c; }
+    // the march addresses the field with a 32-bit byte offset
+    if ((uint64_t)ftgp_plane256(t.width, t.height) * 256u * (uint64_t)n_sectors > 0xFFFFFFFFull)
+        return fail(FTGP_ERR_ARG, "track image too large: the sector box field (2 bytes per pixel and direction sector) must stay below 4 GiB%s");
     if (cfg->env_base < 0) return fail(FTGP_ERR_ARG, "env_base < 0%s");
     if (cfg->lidar_mode != FTGP_LIDAR_RANGEFINDER && cfg->lidar_mode != FTGP_LIDAR_FAKELIDAR) return fail(FTGP_ERR_ARG, "unknown lidar_mode%s");
     if (!(cfg->dt > 0.0) || !(t.px_size_x > 0.0) || !(t.px_size_y > 0.0)) return fail(FTGP_ERR_ARG, "bad dt / pixel size%s");
@@ -414,7 +419,8 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
     P.map_size = cfg->map_size > 0.0 ? cfg->map_size : 40.0;                     // 20 * scale, custom.py:1155,1382
     P.width = t.width; P.height = t.height; P.words_per_row = t.words_per_row; P.fstride = t.width + 2;
     P.plane256 = ftgp_plane256(t.width, t.height);
-    for (uint32_t q = 0; q < FTGP_SECTORS; ++q) ftgp_sector_entry(P.sector_tab[q], q, t.width + 2, P.plane256);
+    P.n_sectors = n_sectors; P.slice_factor = FTGP_SLICE_FACTOR(n_sectors / 8);
+    for (uint32_t q = 0; q < (uint32_t)n_sectors; ++q) ftgp_sector_entry(P.sector_tab[q], q, t.width + 2, P.plane256);
     P.px_size_x = t.px_size_x; P.px_size_y = t.px_size_y; P.origin_x = t.origin_x; P.origin_y = t.origin_y;
     P.inv_px_x = 1.0 / t.px_size_x; P.inv_px_y = 1.0 / t.px_size_y;
     P.inv_px_x_f = (float)P.inv_px_x; P.inv_px_y_f = (float)P.inv_px_y;
@@ -569,14 +575,14 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
         P.edt = e->d_edt; P.fan_dirs = e->d_fan;
     } else {   // sector box field: upload the run lengths, search the boxes on the device
         const size_t plane = (size_t)t.width * t.height;
-        const size_t cells = (size_t)P.plane256 * 128 * FTGP_SECTORS;
+        const size_t cells = (size_t)P.plane256 * 128 * (size_t)P.n_sectors;
         uint16_t* d_runx = nullptr; uint16_t* d_runy = nullptr;
         CREATE_TRY(hipMalloc(&e->d_field, cells * sizeof(uint16_t)));
         CREATE_TRY(hipMalloc(&d_runx, 2 * plane * sizeof(uint16_t)));
         CREATE_TRY(hipMalloc(&d_runy, 2 * plane * sizeof(uint16_t)));
         CREATE_TRY(hipMemcpy(d_runx, tab.runx.data(), 2 * plane * sizeof(uint16_t), hipMemcpyHostToDevice));
         CREATE_TRY(hipMemcpy(d_runy, tab.runy.data(), 2 * plane * sizeof(uint16_t), hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(ftgp_box_field_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, e->stream, d_runx, d_runy, t.width, t.height, e->d_field);
+        hipLaunchKernelGGL(ftgp_box_field_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, e->stream, d_runx, d_runy, t.width, t.height, P.n_sectors, e->d_field);
         CREATE_TRY(hipGetLastError());
         CREATE_TRY(hipStreamSynchronize(e->stream));
         (void)hipFree(d_runx); (void)hipFree(d_runy);

@@ -66,6 +66,8 @@ struct DeviceParams {
     float snap_eps;               // the march re-checks a landing point with the exact comparisons within this distance of a pixel boundary
     uint32_t ray_magic;           // ceil(2^32 / n_rays): pool index -> (car slot, ray) without a division
     uint32_t plane256;            // bytes per (padded) sector plane of the box field / 256
+    int32_t n_sectors;            // direction sectors of this handle's box field: 8 x (1, 2, 4 or 8 slope slices per octant)
+    float slice_factor;           // FTGP_SLICE_FACTOR(n_sectors / 8)
     int32_t contact_reach;        // chessboard reach (pixels) of the wall-contact window; `nearbits` is the wall set dilated by it
     // step-kernel launch shape and LDS layout (byte offsets, all 16-B aligned)
     int32_t cars_per_block, waves_per_block, eighth, win_floats;   // win_floats: floats per LDS scan row: (eighth % 4) + (n_rays - 2*eighth) + 1, padded to 4
@@ -80,7 +82,7 @@ struct DeviceParams {
     int32_t lidar_mode, pad_e;
     int32_t tasks_per_car;        // the sweep's work list per car (lidar_groups): groups of 64 consecutive rays, or pairs of opposite groups
     uint32_t group_magic;         // ceil(2^32 / cars_per_block) (0 for one car per block): group draw -> (rank of the group, car slot) without a division
-    const uint16_t* field;        // [FTGP_SECTORS][height + 2][width + 2] box entries (ftgp_march.h), HBM/L2
+    const uint16_t* field;        // [n_sectors][height + 2][width + 2] box entries (ftgp_march.h), HBM/L2
     const uint32_t* bits;         // [height][words_per_row] wall bitmap
     const uint32_t* nearbits;     // [height][words_per_row] wall bitmap dilated by contact_reach (early-out of the wall contact)
     const void* veh_dev;          // VehLds image (vehicle constants + wheel loads) in HBM

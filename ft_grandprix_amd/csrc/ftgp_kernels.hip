@@ -357,7 +357,7 @@ __device__ __forceinline__ void lidar_pool(const DeviceParams& P, ScalarParams G
                 float ivx, ivy;
                 rcp_abs2(du, dv, ivx, ivy);
                 // `result` stays as set at the top of the sweep (-1); offsets and strides of the ray's sector come out of the LDS table
-                ftgp_ray_init(ray, pu, pv, du, dv, ivx, ivy, W, H, fstride, plane256, true, &P.sector_tab[0][0]);
+                ftgp_ray_init(ray, pu, pv, du, dv, ivx, ivy, W, H, fstride, plane256, true, &P.sector_tab[0][0], G->slice_factor);
                 if (!all_safe) {         // wave-uniform, rare: some car of the workgroup is near the image edge, off it, or has finished
                     ftgp_ray_park_if_outside(ray, pu, pv, W, H);
                     // a finished car's rangefinders are switched off (custom.py:1436-1439): its frame carries u0 = -inf, so the ray is
@@ -547,7 +547,7 @@ __device__ __forceinline__ void lidar_groups(const DeviceParams& P, ScalarParams
     const int W = G->width, H = G->height, fstride = G->fstride, stride = G->ranges_stride;
     const uint32_t plane256 = G->plane256, gmagic = G->group_magic;
     const int eighth = G->eighth, win_floats = G->win_floats;
-    const float isx = G->inv_px_x_f, isy = G->inv_px_y_f, thr = 0.5f - G->snap_eps;
+    const float isx = G->inv_px_x_f, isy = G->inv_px_y_f, thr = 0.5f - G->snap_eps, nsf = G->slice_factor;
     const float r0 = sgpr(L.veh->ring_radius_f);
     const void* field = G->field;
     const global_f32 ranges = (global_f32)G->ranges + (size_t)ci0 * stride;
@@ -620,7 +620,7 @@ __device__ __forceinline__ void lidar_groups(const DeviceParams& P, ScalarParams
             float ivx, ivy;
             rcp_abs2(du, dv, ivx, ivy);
             ray.result = -1.0f;
-            sector = ftgp_ray_sector(du, dv, ivx, ivy);
+            sector = ftgp_ray_sector(du, dv, ivx, ivy, nsf);
             ftgp_ray_place(ray, pu, pv, du, dv, ivx, ivy, sector, W, H, fstride, plane256, true, &P.sector_tab[0][0]);
             if (!all_safe) {             // wave-uniform, rare: some car of the workgroup is near the image edge, off it, or has finished
                 ftgp_ray_park_if_outside(ray, pu, pv, W, H);
@@ -1783,16 +1783,16 @@ __global__ void ftgp_fakelidar_kernel(const double* __restrict__ dt, int H, int 
 }
 
 // Sector box field build (ftgp_create): one cell of one plane per lane, ring included.
-__global__ void ftgp_box_field_kernel(const uint16_t* __restrict__ runx, const uint16_t* __restrict__ runy, int W, int H, uint16_t* __restrict__ out)
+__global__ void ftgp_box_field_kernel(const uint16_t* __restrict__ runx, const uint16_t* __restrict__ runy, int W, int H, int n_sectors, uint16_t* __restrict__ out)
 {
     const size_t cells = (size_t)ftgp_plane256(W, H) * 128;          // 16-bit entries per (padded) plane
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= cells * FTGP_SECTORS) return;
+    if (i >= cells * (size_t)n_sectors) return;
     const int sector = (int)(i / cells);
     const size_t c = i - (size_t)sector * cells;
     const int X = (int)(c % (size_t)(W + 2)), Y = (int)(c / (size_t)(W + 2));
     uint32_t e = FTGP_FIELD_OUT;
-    if (X >= 1 && X <= W && Y >= 1 && Y <= H) e = ftgp_box_entry(runx, runy, W, H, X - 1, Y - 1, sector);
+    if (X >= 1 && X <= W && Y >= 1 && Y <= H) e = ftgp_box_entry(runx, runy, W, H, X - 1, Y - 1, sector, n_sectors / 8);
     out[i] = (uint16_t)e;
 }
 

@@ -9,7 +9,8 @@
 //
 // Sector box field.  Both axes are mirrored so that every ray travels towards +x', +y' (x' = -x is exact in IEEE
 // arithmetic and maps cell i to ~i).  Directions are binned into FTGP_SECTORS = 8 * NS sectors: the octant (mirror x, mirror y,
-// dominant axis) and, inside it, NS equal slices of the slope minor/major (NS = 1, 2, 4 or 8; 8 is shipped).  For each pixel and sector one 16-bit
+// dominant axis) and, inside it, NS equal slices of the slope minor/major (NS = 1, 2, 4 or 8: a handle's choice at ftgp_create --
+// more slices mean fewer march iterations and a larger field; FTGP_SECTORS = 64 is the largest and what the host tools use).  For each pixel and sector one 16-bit
 // entry holds a box of pixels with its corner at the pixel, extending AHEAD of the ray: low byte kx, high byte ky (cells
 // along x' / y'); 0 = the pixel is a wall.  Only the part of the box that a ray of the sector can reach from anywhere
 // inside the pixel has to be wall-free (the cone of the sector, widened by one cell so that rays through pixel corners --
@@ -51,12 +52,12 @@ static_assert(FTGP_SECTORS == 8 || FTGP_SECTORS == 16 || FTGP_SECTORS == 32 || F
 // [qa / NS, qb / NS] can only be in row j of column i if  lo * (i - 1) - 1 <= j <= hi * (i + 1) + 1  (closed: corner touches count).  For every
 // box height kB the widest admissible kA is the first wall met by the reachable part of rows 0 .. kB - 1; the pair that
 // maximises the travel min(kA, kB / slope) summed over four slopes of the sector is stored.
-FTGP_HD uint32_t ftgp_box_entry(const uint16_t* runx, const uint16_t* runy, int W, int H, int x, int y, int sector)
+FTGP_HD uint32_t ftgp_box_entry(const uint16_t* runx, const uint16_t* runy, int W, int H, int x, int y, int sector, int NS = FTGP_SLOPE_SLICES)
 {
     const size_t plane = (size_t)W * H;
     if (runx[(size_t)y * W + x] == 0) return 0u;                 // wall
     const int q = sector & 3, dom = (sector >> 2) & 1;
-    const int NS = FTGP_SLOPE_SLICES, qa = sector >> 3, qb = qa + 1;
+    const int qa = sector >> 3, qb = qa + 1;                     // NS = slope slices per octant (a handle's choice: ftgp_create)
     const int sx = (q & 1) ? -1 : 1, sy = (q & 2) ? -1 : 1;
     const int ax = dom == 0 ? sx : 0, ay = dom == 0 ? 0 : sy;    // unit step along the major / minor axis
     const int bx = dom == 0 ? 0 : sx, by = dom == 0 ? sy : 0;
@@ -141,7 +142,9 @@ FTGP_HD void ftgp_sector_entry(int32_t* e, uint32_t sector, int fstride, uint32_
 
 // Sector of a direction: (mirror x) | (mirror y) << 1 | (y-dominant) << 2 | (slope slice) << 3.  Mirrors and dominant axis come out of
 // sign bits and one compare; the OPPOSITE direction (-du, -dv) has exactly this sector with the two mirror bits flipped (sector ^ 3).
-FTGP_HD uint32_t ftgp_ray_sector(float du, float dv, float ivx, float ivy)
+// nsf = (slope slices per octant) * 0.99999: the slice of a ray is floor(minor / major * nsf).
+#define FTGP_SLICE_FACTOR(ns) ((float)(ns) * 0.99999f)
+FTGP_HD uint32_t ftgp_ray_sector(float du, float dv, float ivx, float ivy, float nsf = FTGP_SLICE_FACTOR(FTGP_SLOPE_SLICES))
 {
     // A direction component of -0 mirrors its axis too: harmless, the ray never steps along it.  (The dominant axis stays a compare
     // and two selects: fminf / fmaxf bring canonicalising v_max x, x, x along, and integer min / max on the bit patterns cost what the
@@ -150,13 +153,13 @@ FTGP_HD uint32_t ftgp_ray_sector(float du, float dv, float ivx, float ivy)
     const float adu = fabsf(du), adv = fabsf(dv);
     const bool ydom = !(adu >= adv);
     uint32_t sector = (bu >> 31) | ((bv >> 31) << 1) | (ydom ? 4u : 0u);
-    if (FTGP_SLOPE_SLICES > 1) {
+    {
         // slope slice = floor(NS * minor / major), with the reciprocal of the major component that is at hand anyway.  A few units
         // of rounding may put a ray that runs along a slice boundary into the neighbouring slice: harmless, the boxes of a
         // slice hold for every slope within a cell's margin of it (ftgp_box_entry), and a box that holds gives the
         // specification's result whichever slice it came from.  The factor just below NS keeps slope 1 in the last slice.
         const float mn = ydom ? adu : adv, inv_mj = ydom ? ivy : ivx;
-        const float scaled = (mn * inv_mj) * ((float)FTGP_SLOPE_SLICES * 0.99999f);
+        const float scaled = (mn * inv_mj) * nsf;             // (one slice per octant: the factor is below 1 and the slice 0)
 #if defined(__HIP_DEVICE_COMPILE__)
         int slice; asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(slice) : "v"(scaled));
 #else
@@ -217,9 +220,9 @@ FTGP_HD void ftgp_ray_place(FtgpRay& r, float pu, float pv, float du, float dv, 
 }
 
 FTGP_HD void ftgp_ray_init(FtgpRay& r, float pu, float pv, float du, float dv, float ivx, float ivy, int W, int H, int fstride, uint32_t plane256,
-                           bool assume_inside = false, const int32_t* sector_tab = nullptr)
+                           bool assume_inside = false, const int32_t* sector_tab = nullptr, float nsf = FTGP_SLICE_FACTOR(FTGP_SLOPE_SLICES))
 {
-    ftgp_ray_place(r, pu, pv, du, dv, ivx, ivy, ftgp_ray_sector(du, dv, ivx, ivy), W, H, fstride, plane256, assume_inside, sector_tab);
+    ftgp_ray_place(r, pu, pv, du, dv, ivx, ivy, ftgp_ray_sector(du, dv, ivx, ivy, nsf), W, H, fstride, plane256, assume_inside, sector_tab);
 }
 
 // The on-image test of ftgp_ray_init for a caller that initialised with assume_inside although it could not promise it:

@@ -441,6 +441,27 @@ def test_custom_fan_takes_the_unpaired_sweep(product, oracle, R, cars):
         np.testing.assert_array_equal(single.pose(), paired.pose())
 
 
+@pytest.mark.parametrize("sectors", [8, 16, 32, 64])
+def test_results_do_not_depend_on_the_sector_count(product, oracle, sectors):
+    """ftgp_create picks the number of direction sectors of the box field by batch size (16 for large batches, 64 for small ones);
+    FTGP_SECTORS_RT forces it.  Any choice must give the specification's ranges: closed loop against the oracle, two tracks
+    (square and stretched pixels), single- and multi-car."""
+    import os
+    os.environ["FTGP_SECTORS_RT"] = str(sectors)
+    try:
+        for name, cars, policy in (("track", 1, "fast"), ("inkscape", 3, "nidc")):
+            t = load_track(name)
+            g, o = both(product, oracle, t, n_envs=24, cars_per_env=cars, n_rays=1080, spawn_mode=1, seed=sectors)
+            with g, o:
+                for n in (1, 120, 400):
+                    g.rollout(policy, n); o.rollout(policy, n)
+                    np.testing.assert_array_equal(g.lidar(), o.lidar())
+                    np.testing.assert_array_equal(g.progress(), o.progress())
+                    np.testing.assert_allclose(g.pose(), o.pose(), rtol=0, atol=1e-12)
+    finally:
+        del os.environ["FTGP_SECTORS_RT"]
+
+
 def test_gpu_shards_reproduce_the_monolithic_batch(product):
     """a shard [env_base, env_base + n) must equal the same slice of the whole batch (two handles, one GPU)."""
     from ft_grandprix_amd import dist as ftdist
