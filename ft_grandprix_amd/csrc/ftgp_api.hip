@@ -205,6 +205,8 @@ int lds_layout(DeviceParams& P, int cpb, int wpb)
     P.off_list = o;   o += std::min(cpb, wpb) * FTGP_WAVE * (int)sizeof(int);                 // driver scratch: wave c runs the driver of car c
     P.off_pool = o;   o += 32;
     P.off_k1 = o;     o += cpb * (FTGP_FORCE_TERMS * 24 + 4 * 8 + 104);                         // K1 staging: force terms | new wheel spins | new state
+    P.mmask_stride = pad16((size_t)2 * (size_t)((P.n_rays + FTGP_WAVE - 1) / FTGP_WAVE + 2));      // two groups per task, never more tasks than groups of 64 rays + 2
+    P.off_mmask = o;  if (P.cars_per_env > 1) o += 2 * cpb * P.mmask_stride;              // env-mate visibility masks, double-buffered by step parity
     P.off_cover = o;  o += pad16(sizeof(float) * (size_t)(P.cover_kmax + 1));             // cover-count thresholds of the launch's driver (last: its size = lds_bytes - off_cover)
     P.lds_bytes = o;
     P.cars_per_block = cpb; P.waves_per_block = wpb;
@@ -546,6 +548,11 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
         }
         P.tasks_per_car = (int)order.size();
         for (size_t k = 0; k < order.size(); ++k) P.group_order[k] = order[k];
+        // mate_masks(): a ray of a group lies within 32 spacings of the rangefinders' uniform fan of the group's middle ray; + 1.2 degrees for the
+        // slack in the rays' own test (acos 0.9999 = 0.81 degrees) and rounding.  A caller's fan has no such bound: every mate is looked at.
+        const double gamma = 32.0 * (2.0 * M_PI / (double)R) + 0.021;
+        if (cfg->fan_dirs || gamma >= 1.5) { P.group_cg = -2.0f; P.group_sg = 0.0f; }
+        else { P.group_cg = (float)cos(gamma); P.group_sg = (float)sin(gamma); }
         if (getenv("FTGP_VERBOSE")) fprintf(stderr, "ftgp_create: %d sweep tasks per car (%s)\n", P.tasks_per_car, sym ? "pairs of opposite ray groups" : "single groups");
     }
     std::vector<double> spawn(4 * FTGP_PATH_POINTS);

@@ -72,6 +72,7 @@ struct DeviceParams {
     // step-kernel launch shape and LDS layout (byte offsets, all 16-B aligned)
     int32_t cars_per_block, waves_per_block, eighth, win_floats;   // win_floats: floats per LDS scan row: (eighth % 4) + (n_rays - 2*eighth) + 1, padded to 4
     int32_t off_params, off_veh, off_path, off_ray, off_cars, off_frame, off_steps, off_scan, off_list, off_pool, off_k1, off_cover, lds_bytes, cover_kmax;
+    int32_t off_mmask, mmask_stride;      // multi-car envs: [2][cars_per_block][mmask_stride] bytes, which env-mates a ray group can see (mate_masks)
     int32_t bubble_wrap;          // custom.py:1041-1055: the four wheel softeners collide with the walls
     int32_t n_cu, pad_c;          // compute units of the device (sweep_priority)
     float edge_margin, pad_d;     // pixels: a LiDAR centre at least this far from every image edge has all its ray origins on the image (frame_write)
@@ -81,6 +82,7 @@ struct DeviceParams {
     double map_size;              // 20 * scale = 40 (custom.py:1382)
     int32_t lidar_mode, pad_e;
     int32_t tasks_per_car;        // the sweep's work list per car (lidar_groups): groups of 64 consecutive rays, or pairs of opposite groups
+    float group_cg, group_sg;     // cos / sin of the half-width of a ray group as mate_masks() needs it (cg < -1: no bound, e.g. a caller's fan)
     uint32_t group_magic;         // ceil(2^32 / cars_per_block) (0 for one car per block): group draw -> (rank of the group, car slot) without a division
     const uint16_t* field;        // [n_sectors][height + 2][width + 2] box entries (ftgp_march.h), HBM/L2
     const uint32_t* bits;         // [height][words_per_row] wall bitmap

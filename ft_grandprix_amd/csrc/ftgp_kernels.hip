@@ -49,6 +49,7 @@ struct Lds {
     double* wnew;             // [cars_per_block][4] K1 staging: new wheel spins
     Dyn* next;                // [cars_per_block] K1 staging: new dynamic state before the commit
     const float* cover;       // [cover_kmax + 1] cover-count thresholds of the launch's driver (see cover_count)
+    unsigned char* mmask;     // [2][cars_per_block][mmask_stride] multi-car envs: which env-mates each ray group of a car can see (mate_masks)
 };
 
 // LDS scan window of one car: the samples the on-device drivers read.  Sample ranges[eighth + i] sits at float index
@@ -74,14 +75,14 @@ __device__ __forceinline__ ScalarParams scalar_view(const DeviceParams* p)
 // that needs them instead of being hoisted in front of the step loop and carried -- spilled -- across the sweep
 __device__ __forceinline__ int lane_here() { int l = lane_id(); asm volatile("" : "+v"(l)); return l; }
 
-struct LdsOffsets { int params, veh, path, ray, cars, frame, steps, scan, list, pool, k1, cover, cpb; };
+struct LdsOffsets { int params, veh, path, ray, cars, frame, steps, scan, list, pool, k1, cover, mmask, cpb; };
 
 __device__ __forceinline__ LdsOffsets lds_offsets(const DeviceParams& P)
 {
     LdsOffsets o;
     o.params = sgpr(P.off_params); o.veh = sgpr(P.off_veh); o.path = sgpr(P.off_path); o.ray = sgpr(P.off_ray); o.cars = sgpr(P.off_cars);
     o.frame = sgpr(P.off_frame); o.steps = sgpr(P.off_steps); o.scan = sgpr(P.off_scan); o.list = sgpr(P.off_list); o.pool = sgpr(P.off_pool);
-    o.k1 = sgpr(P.off_k1); o.cover = sgpr(P.off_cover); o.cpb = sgpr(P.cars_per_block);
+    o.k1 = sgpr(P.off_k1); o.cover = sgpr(P.off_cover); o.mmask = sgpr(P.off_mmask); o.cpb = sgpr(P.cars_per_block);
     return o;
 }
 
@@ -90,7 +91,7 @@ __device__ __forceinline__ LdsOffsets lds_offsets(ScalarParams G)
     LdsOffsets o;
     o.params = G->off_params; o.veh = G->off_veh; o.path = G->off_path; o.ray = G->off_ray; o.cars = G->off_cars;
     o.frame = G->off_frame; o.steps = G->off_steps; o.scan = G->off_scan; o.list = G->off_list; o.pool = G->off_pool;
-    o.k1 = G->off_k1; o.cover = G->off_cover; o.cpb = G->cars_per_block;
+    o.k1 = G->off_k1; o.cover = G->off_cover; o.mmask = G->off_mmask; o.cpb = G->cars_per_block;
     return o;
 }
 
@@ -120,6 +121,7 @@ __device__ __forceinline__ Lds lds_view(const LdsOffsets& o, unsigned char* lds)
     L.wnew = reinterpret_cast<double*>(k1 + o.cpb * (int)(FTGP_FORCE_TERMS * sizeof(Force)));
     L.next = reinterpret_cast<Dyn*>(k1 + o.cpb * (int)(FTGP_FORCE_TERMS * sizeof(Force) + 4 * sizeof(double)));
     L.cover = reinterpret_cast<const float*>(lds + opaque(o.cover));
+    L.mmask = lds + opaque(o.mmask);
     return L;
 }
 
@@ -538,8 +540,8 @@ __device__ __forceinline__ void march_all(int& ix, int& iy, float& s, uint32_t& 
 // slope slice (the two divisions and the sector search are half of a set-up) and only places its rays anew (ftgp_ray_place with
 // sector ^ 3).  Tasks are drawn long-first across the workgroup's cars (group_order), so that the waves end a sweep together.
 template <bool MULTI>
-__device__ __forceinline__ void lidar_groups(const DeviceParams& P, ScalarParams G, const Lds& L, const LidarFrame* frames, const PairCull* pairs, float* scan_rows, int* pool,
-                                             int ncars_here, int ci0, bool scan_lds, bool second_half STAMP_ARG)
+__device__ __forceinline__ void lidar_groups(const DeviceParams& P, ScalarParams G, const Lds& L, const LidarFrame* frames, const PairCull* pairs, const unsigned char* mmask,
+                                             float* scan_rows, int* pool, int ncars_here, int ci0, bool scan_lds, bool second_half STAMP_ARG)
 {
     typedef __attribute__((address_space(1))) float* global_f32;
     typedef __attribute__((address_space(1))) unsigned char* global_u8w;
@@ -551,7 +553,7 @@ __device__ __forceinline__ void lidar_groups(const DeviceParams& P, ScalarParams
     const float r0 = sgpr(L.veh->ring_radius_f);
     const void* field = G->field;
     const global_f32 ranges = (global_f32)G->ranges + (size_t)ci0 * stride;
-    const int cars_per_env = G->cars_per_env;
+    const int mmask_stride = G->mmask_stride;
     const int lane = lane_here();
     const bool all_safe = sgpr(pool[4]) == 0;        // every ray of this sweep starts on the image (frame_write): no test per ray
     sweep_priority(second_half);
@@ -574,19 +576,26 @@ __device__ __forceinline__ void lidar_groups(const DeviceParams& P, ScalarParams
         float du = 0.0f, dv = 0.0f, dxw = 0.0f, dyw = 0.0f;
         uint32_t sector = 0;
         // march the lanes' rays and deliver their ranges: ftgp_ray_range(), the inter-vehicle test, the stores
-        auto finish = [&](bool active) {
+        auto finish = [&](bool active, int pass) {
             if (!active) return;
             uint32_t w = FTGP_FIELD_OUT;
             STAMP(tb);
             march_all(ray.ix, ray.iy, ray.s, w, ray.pum, ray.pvm, ray.ivx, ray.ivy, ray.dum, ray.dvm, ray.offC, ray.ax, ray.ay, thr, field);
             STAMP(tc); STAMP_ADD(10, tc - tb); STAMP_ADD(9, 1);
             float r = (w == 0u) ? fabsf(ray.s) : ray.result;
+#ifdef FTGP_ABLATE_MATES      // diagnostic (timing only, wrong results): what the inter-vehicle tests cost
+            if (false) {
+#else
             if (MULTI) {
+#endif
                 // Rays also see the other cars of the env (a9).  One record per env-mate (PairCull, written with the frames) rules a
                 // mate out with a dot product: it can only be touched if it lies in front of the ray and within `cull` of its line.
                 const PairCull* mates = pairs + c * FTGP_PAIR_STRIDE;
                 const int slot0 = sgpr(frames[c].slot0);
-                for (int k = 0; k < cars_per_env; ++k) {
+                // ... and one byte per (car, group) says which mates the group's rays can see at all (mate_masks): mostly none
+                uint32_t mm = (uint32_t)sgpr((int)mmask[c * mmask_stride + 2 * kidx + pass]);
+                while (mm) {
+                    const int k = __builtin_ctz(mm); mm &= mm - 1u;
                     const float4 q = *reinterpret_cast<const float4*>(mates + k);
                     const float al = fmaf(q.x, dxw, q.y * dyw);
                     if (al >= q.z) {
@@ -630,7 +639,7 @@ __device__ __forceinline__ void lidar_groups(const DeviceParams& P, ScalarParams
             }
         }
         STAMP(td); STAMP_ADD(8, td - ta);
-        finish(mine);
+        finish(mine, 0);
         if (kind == 1) {                 // the same rays turned round: ray j + n/2 = -(ray j), exactly
             if (mine) {
                 j += half;
@@ -644,7 +653,7 @@ __device__ __forceinline__ void lidar_groups(const DeviceParams& P, ScalarParams
                     ray.result = (f4.x == -INFINITY) ? 0.0f : -1.0f;
                 }
             }
-            finish(mine);
+            finish(mine, 1);
         }
     }
 }
@@ -986,6 +995,41 @@ __device__ __forceinline__ void pair_cull_write(const LidarFrame* frames, PairCu
     pairs[c * FTGP_PAIR_STRIDE + k] = p;
 }
 
+// Multi-car envs: which env-mates can the rays of a GROUP see?  The sweep tests a ray against a mate only if the mate lies inside the
+// ray's cone (PairCull); most groups of 64 neighbouring rays look nowhere near any mate, and finding that out ray by ray -- a record
+// read, a dot product, a compare and a wave-wide vote per mate and group -- was a third of the multi-car sweep.  So it is decided once
+// per (car, group, mate), lane-parallel, by the wave that has just written the frames: a ray of the group lies within 32 ray
+// spacings (10.7 degrees at 1080 rays; the bound below is computed for the actual fan spacing) of the group's middle ray d_g, so it can
+// only pass its own test  B . d >= t  if  B . d_g >= cos(gamma) t - sin(gamma) cull  (cos of a sum of angles), gamma = that half-width
+// plus what the 0.9999 in t and binary32 rounding can add.  One byte per (car, group): bit k = env-mate k may be visible.  A mask that
+// says "may" too often costs time, never a result: the exact tests follow.
+typedef const __attribute__((address_space(4))) int32_t* ScalarInts;
+__device__ __forceinline__ void mate_masks(const LidarFrame* frames, const PairCull* pairs, unsigned char* mmask, int mmask_stride, ScalarInts order,
+                                           const float2* __restrict__ ray_tab, int R, int tasks, int cars_per_env, float cull, float cg, float sg,
+                                           int ncars_here, int first, int step)
+{
+    const int slots = 2 * tasks;
+    for (int idx = first; idx < ncars_here * slots; idx += step) {
+        const int c = idx / slots, s = idx - c * slots;
+        const int ent = order[s >> 1], j0 = ent & 0xffff, kind = ent >> 16;
+        uint32_t m = 0;
+        if (kind == 2 || cg < -1.0f) m = (s & 1) ? 0u : 0xffu;                // both half-fans in one group, or a fan the bound does not cover: look at every mate
+        else if (!(s & 1) || kind == 1) {
+            const int jc = min(j0 + 32, (kind == 1 ? (R >> 1) : R) - 1);
+            const float2 bd = ray_tab[jc];
+            const LidarFrame* me = frames + c;
+            float dxw = fmaf(me->chf, bd.x, -(me->shf * bd.y)), dyw = fmaf(me->shf, bd.x, me->chf * bd.y);
+            if (s & 1) { dxw = -dxw; dyw = -dyw; }                                   // the opposite group
+            for (int k = 0; k < cars_per_env; ++k) {
+                const float4 q = *reinterpret_cast<const float4*>(pairs + c * FTGP_PAIR_STRIDE + k);
+                const float al = fmaf(q.x, dxw, q.y * dyw);
+                if (al >= fmaf(cg, q.z, -(sg * cull)) - 1e-4f) m |= 1u << k;          // (t = +inf: never -- myself, a finished car; t = -inf: always)
+            }
+        }
+        mmask[c * mmask_stride + s] = (unsigned char)m;
+    }
+}
+
 // K1 + K3 for every car of the workgroup by ONE wave, four lanes per car (lane = 4 * car + r).
 //   K1  lane r evaluates wheel r (fl, fr, bl, br), then wall-contact circle r (r < 3), then wheel softener r (bubble_wrap);
 //       the force terms go to an LDS staging row and lane 0 of the car adds them up in the specification's order
@@ -996,7 +1040,8 @@ __device__ __forceinline__ void pair_cull_write(const LidarFrame* frames, PairCu
 //       followed by the head of the next loop iteration.
 // Then the LiDAR frames of the next step are written.
 template <bool MULTI>
-__device__ __forceinline__ void dynamics_lanes(const DeviceParams& P, const Lds& L, LidarFrame* next_frames, PairCull* next_pairs, int* unsafe_next, int ncars_here, int ci0)
+__device__ __forceinline__ void dynamics_lanes(const DeviceParams& P, const Lds& L, LidarFrame* next_frames, PairCull* next_pairs, unsigned char* next_mmask, ScalarInts order,
+                                               int* unsafe_next, int ncars_here, int ci0)
 {
     const int lane = lane_here();
     const int c = lane >> 2, r = lane & 3;
@@ -1143,6 +1188,8 @@ __device__ __forceinline__ void dynamics_lanes(const DeviceParams& P, const Lds&
             pair_cull_write(next_frames, next_pairs, c, r, P.cars_per_env, cull, r0f);
             pair_cull_write(next_frames, next_pairs, c, r + 4, P.cars_per_env, cull, r0f);
         }
+        wave_lds_sync();
+        mate_masks(next_frames, next_pairs, next_mmask, P.mmask_stride, order, L.ray, P.n_rays, P.tasks_per_car, P.cars_per_env, cull, P.group_cg, P.group_sg, ncars_here, lane, FTGP_WAVE);
     }
 }
 
@@ -1519,6 +1566,10 @@ __global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(cons
         __syncthreads();
         const int c = (int)threadIdx.x / FTGP_PAIR_STRIDE, k = (int)threadIdx.x % FTGP_PAIR_STRIDE;
         if (c < ncars_here) pair_cull_write(L.frame, L.pairs, c, k, P.cars_per_env, L.veh->cull_radius, (float)L.veh->v.lidar_ring_radius);
+        __syncthreads();
+        if (wave == 0)
+            mate_masks(L.frame, L.pairs, L.mmask, P.mmask_stride, &scalar_view(Pg)->group_order[0], L.ray, P.n_rays, P.tasks_per_car, P.cars_per_env, L.veh->cull_radius, P.group_cg, P.group_sg,
+                       ncars_here, lane_here(), FTGP_WAVE);
     }
     }
     __syncthreads();
@@ -1559,14 +1610,15 @@ __global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(cons
                 // "my controls are in LDS" -> the wave that counts last reads every car's controls: release on this side (the
                 // fence of wave_lds_sync() + the RMW), acquire on the reader's (the RMW + the fence below), workgroup scope
                 int n = 0;
-                if (lane == 0) n = __hip_atomic_fetch_add(L.pool + 2 + par, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (lane_here() == 0) n = __hip_atomic_fetch_add(L.pool + 2 + par, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
                 n = __builtin_amdgcn_readfirstlane(n);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 STAMP(t1); STAMP_ADD(0, t1 - t0);
                 if (n == ncars_here - 1) {            // every driver of the workgroup has delivered its controls
-                    if (lane == 0) { L.pool[par ^ 1] = 0; L.pool[2 + (par ^ 1)] = 0; }     // the next step's counters (idle during this step)
+                    if (lane_here() == 0) { L.pool[par ^ 1] = 0; L.pool[2 + (par ^ 1)] = 0; }     // the next step's counters (idle during this step)
 #ifndef FTGP_ABLATE_K1
-                    dynamics_lanes<MULTI>(P, L, next_frames, L.pairs + (par ^ 1) * cpb * FTGP_PAIR_STRIDE, L.pool + 4 + (par ^ 1), ncars_here, ci0);
+                    dynamics_lanes<MULTI>(P, L, next_frames, L.pairs + (par ^ 1) * cpb * FTGP_PAIR_STRIDE, L.mmask + (par ^ 1) * cpb * G->mmask_stride, &G->group_order[0],
+                                          L.pool + 4 + (par ^ 1), ncars_here, ci0);
 #endif
                     STAMP(t2); STAMP_ADD(2, t2 - t1); STAMP_ADD(7, 1);
                 }
@@ -1586,7 +1638,8 @@ __global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(cons
 #ifdef FTGP_SWEEP_V1
             else lidar_pool<MULTI>(P, G, L, L.frame + par * cpb, L.pairs + par * cpb * FTGP_PAIR_STRIDE, L.scan + par * cpb * G->win_floats, L.pool + par, ncars_here, ci0, need_scan, second_half STAMP_PASS);
 #else
-            else lidar_groups<MULTI>(P, G, L, L.frame + par * cpb, L.pairs + par * cpb * FTGP_PAIR_STRIDE, L.scan + par * cpb * G->win_floats, L.pool + par, ncars_here, ci0, need_scan, second_half STAMP_PASS);
+            else lidar_groups<MULTI>(P, G, L, L.frame + par * cpb, L.pairs + par * cpb * FTGP_PAIR_STRIDE, L.mmask + par * cpb * G->mmask_stride, L.scan + par * cpb * G->win_floats,
+                                     L.pool + par, ncars_here, ci0, need_scan, second_half STAMP_PASS);
 #endif
         }
 #endif
@@ -1597,7 +1650,7 @@ __global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(cons
     }
 
 #ifdef FTGP_STAMPS
-    if (lane == 0) for (int q = 0; q < 12; ++q) atomicAdd(&ftgp_stamps[q], stamp_acc[q]);
+    if (lane_here() == 0) for (int q = 0; q < 12; ++q) atomicAdd(&ftgp_stamps[q], stamp_acc[q]);
 #endif
     const DeviceParams& P = P0;
     const LdsOffsets off_end = lds_offsets(scalar_view(Pg));
@@ -1608,9 +1661,9 @@ __global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(cons
         if (!FAKE && need_scan && n_steps > 0)          // the last sweep's window
             window_flush(&P, L.scan + (((n_steps - 1) & 1) * cpb + c) * P.win_floats, ci);
 #endif
-        if (lane < (int)(sizeof(CarCore) / 4))
-            reinterpret_cast<uint32_t*>(static_cast<CarCore*>(&P.cars[ci]))[lane] = reinterpret_cast<const uint32_t*>(L.cars + c)[lane];
-        if (lane == 0 && ci % P.cars_per_env == 0) P.steps[ci / P.cars_per_env] = L.steps[c];
+        if (lane_here() < (int)(sizeof(CarCore) / 4))
+            reinterpret_cast<uint32_t*>(static_cast<CarCore*>(&P.cars[ci]))[lane_here()] = reinterpret_cast<const uint32_t*>(L.cars + c)[lane_here()];
+        if (lane_here() == 0 && ci % P.cars_per_env == 0) P.steps[ci / P.cars_per_env] = L.steps[c];
     }
     if (P.wg_metrics) {                  // the scan windows are dead now: their first bytes serve as the reduction scratch
         __syncthreads();
