@@ -71,7 +71,7 @@ struct FtgpEnv {
     FtgpConfig cfg{};
     int device = 0;
     hipStream_t stream = nullptr, side = nullptr;
-    hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_metrics = nullptr, ev_gather = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop[2] = { nullptr, nullptr }, ev_metrics = nullptr, ev_gather = nullptr;      // ev_stop: one per metrics slot
     bool timed = false;
     // device buffers
     uint16_t* d_field = nullptr; uint32_t* d_bits = nullptr; uint32_t* d_nearbits = nullptr;
@@ -89,6 +89,9 @@ struct FtgpEnv {
     double* h_gather = nullptr;       // pinned [world][FTGP_METRIC_DOUBLES]: landing buffer of the all-gather
     bool gather_open = false;         // ftgp_metrics_allgather_begin without its _end
     int gather_slot = 0;              // the slot that exchange reads
+    hipEvent_t gather_event = nullptr;   // what its _end waits for: ev_gather (side stream / metrics kernel) or the slot's own ev_stop
+    bool gather_held = false;         // one rank: the record was copied to `held` because a later launch was about to reuse its slot
+    double held[FTGP_METRIC_DOUBLES] = { 0 };
     int32_t* d_prog = nullptr; double* d_core = nullptr;
     std::vector<int32_t> h_prog; std::vector<double> h_core;
     bool rows_valid = false;          // h_prog / h_core mirror the device state (cleared by every call that changes it)
@@ -225,8 +228,16 @@ int launch_steps(FtgpEnv* e, int policy, int n_steps)
     const int cpb = e->P.cars_per_block;
     const int blocks = (e->P.n_cars + cpb - 1) / cpb;
     const int slot = e->cur_slot ^ 1;
-    // an exchange that is still reading this launch's slot (begin without end, two launches ago) goes first -- on the device
-    if (n_steps > 0 && e->gather_open && e->gather_slot == slot) HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_gather, 0));
+    // an exchange that is still reading this launch's slot (begin without end, two launches ago) goes first: over RCCL on the device (the
+    // side stream's event); with one rank the "exchange" is the record in pinned memory, which is put aside before the slot is reused
+    if (n_steps > 0 && e->gather_open && e->gather_slot == slot) {
+        if (e->comm) HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_gather, 0));
+        else if (!e->gather_held) {
+            HIP_TRY(hipEventSynchronize(e->gather_event));
+            memcpy(e->held, e->h_metrics + (size_t)slot * FTGP_METRIC_DOUBLES, sizeof e->held);
+            e->gather_held = true;
+        }
+    }
     HIP_TRY(hipEventRecord(e->ev_start, e->stream));
     if (n_steps > 0) {
         const dim3 grid(blocks), block(e->P.waves_per_block * FTGP_WAVE);
@@ -240,7 +251,7 @@ int launch_steps(FtgpEnv* e, int policy, int n_steps)
         e->cur_slot = slot;
         e->launch_metrics_valid = e->d_wg_metrics != nullptr;
     }
-    HIP_TRY(hipEventRecord(e->ev_stop, e->stream));
+    HIP_TRY(hipEventRecord(e->ev_stop[e->cur_slot], e->stream));
     e->timed = true;
     return 0;
 }
@@ -349,7 +360,7 @@ int ftgp_destroy(FtgpEnv* e)
     if (e->h_gather) (void)hipHostFree(e->h_gather);
     if (e->ev_gather) (void)hipEventDestroy(e->ev_gather);
     if (e->ev_start) (void)hipEventDestroy(e->ev_start);
-    if (e->ev_stop) (void)hipEventDestroy(e->ev_stop);
+    for (hipEvent_t ev : e->ev_stop) if (ev) (void)hipEventDestroy(ev);
     if (e->ev_metrics) (void)hipEventDestroy(e->ev_metrics);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     if (e->side) (void)hipStreamDestroy(e->side);
@@ -406,7 +417,8 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
     CREATE_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     CREATE_TRY(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
     CREATE_TRY(hipEventCreate(&e->ev_start));
-    CREATE_TRY(hipEventCreate(&e->ev_stop));
+    CREATE_TRY(hipEventCreate(&e->ev_stop[0]));
+    CREATE_TRY(hipEventCreate(&e->ev_stop[1]));
     CREATE_TRY(hipEventCreateWithFlags(&e->ev_metrics, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&e->ev_gather, hipEventDisableTiming));
 
@@ -931,8 +943,10 @@ int ftgp_metrics_allgather_begin(FtgpEnv* e)
         hipLaunchKernelGGL(ftgp_metrics_kernel, dim3(1), dim3(FTGP_METRIC_THREADS), 0, e->stream, e->P, rccl ? e->d_metrics + so : e->h_metrics_dev + so);
         HIP_TRY(hipGetLastError());
     }
+    e->gather_held = false;
     if (!rccl) {                         // one rank: the "exchange" is the record's arrival in pinned memory
-        HIP_TRY(hipEventRecord(e->ev_gather, e->stream));
+        if (e->launch_metrics_valid && e->timed) e->gather_event = e->ev_stop[slot];      // ... with the launch that wrote it: nothing to enqueue
+        else { HIP_TRY(hipEventRecord(e->ev_gather, e->stream)); e->gather_event = e->ev_gather; }
     } else {
         // the record is produced on the compute stream; everything else happens on the side stream, beside the next launch
         HIP_TRY(hipEventRecord(e->ev_metrics, e->stream));
@@ -941,6 +955,7 @@ int ftgp_metrics_allgather_begin(FtgpEnv* e)
         if (r != 0) return fail(FTGP_ERR_COMM, "ncclAllGather: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
         HIP_TRY(hipMemcpyAsync(e->h_gather, e->d_gather, sizeof(double) * FTGP_METRIC_DOUBLES * (size_t)e->world, hipMemcpyDeviceToHost, e->side));
         HIP_TRY(hipEventRecord(e->ev_gather, e->side));
+        e->gather_event = e->ev_gather;
     }
     e->gather_open = true; e->gather_slot = slot;
     return 0;
@@ -951,9 +966,10 @@ int ftgp_metrics_allgather_end(FtgpEnv* e, double* out)
     if (!e || !out) return fail(FTGP_ERR_ARG, "null argument%s");
     if (!e->gather_open) return fail(FTGP_ERR_STATE, "ftgp_metrics_allgather_end without _begin%s");
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipEventSynchronize(e->ev_gather));          // this exchange only: a later launch on the compute stream is not waited for
+    if (!e->gather_held) HIP_TRY(hipEventSynchronize(e->gather_event));      // this exchange only: a later launch on the compute stream is not waited for
     e->gather_open = false;
     if (e->comm) memcpy(out, e->h_gather, sizeof(double) * FTGP_METRIC_DOUBLES * (size_t)e->world);
+    else if (e->gather_held) memcpy(out, e->held, sizeof e->held);
     else memcpy(out, e->h_metrics + (size_t)e->gather_slot * FTGP_METRIC_DOUBLES, sizeof(double) * FTGP_METRIC_DOUBLES);
     return 0;
 }
@@ -1008,8 +1024,8 @@ int ftgp_last_kernel_ms(FtgpEnv* e, float* ms)
     if (!e || !ms) return fail(FTGP_ERR_ARG, "null argument%s");
     if (!e->timed) return fail(FTGP_ERR_STATE, "no step/rollout has been launched yet%s");
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipEventSynchronize(e->ev_stop));
-    HIP_TRY(hipEventElapsedTime(ms, e->ev_start, e->ev_stop));
+    HIP_TRY(hipEventSynchronize(e->ev_stop[e->cur_slot]));
+    HIP_TRY(hipEventElapsedTime(ms, e->ev_start, e->ev_stop[e->cur_slot]));
     return 0;
 }
 

@@ -1421,7 +1421,8 @@ __device__ __forceinline__ void policy_apply(const DeviceParams& P, const Driver
 // form of the CDNA guide with write-through stores: ONE lane stores its workgroup's record with agent-scope (sc1) stores, waits
 // for them and draws a ticket (relaxed agent-scope fetch_add); the workgroup that draws the last ticket takes an agent-scope
 // acquire fence, waits, passes a barrier and reads the records.  (A release fence per workgroup instead -- an L2 write-back
-// each -- cost 14 us per launch, as much as the separate kernel.)
+// each -- cost 14 us per launch, as much as the separate kernel.  Tickets in two levels -- eight per-XCD counters, then a top one --
+// changed nothing: the 7 us this costs per launch are the tail of the last workgroup, not the 512 atomics on one word.)
 __device__ __forceinline__ double wave_sum_f64(double v)
 {
     #pragma unroll
