@@ -428,6 +428,7 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
     P.ranges_stride = (cfg->n_rays + 31) & ~31;      // rows start on 128-B boundaries
     P.seed = cfg->seed; P.dt = cfg->dt;
     P.rpp = (2 * M_PI) / (double)cfg->n_rays;
+    P.two_over_rpp = (float)(2.0 / P.rpp);
     P.bubble_wrap = cfg->bubble_wrap ? 1 : 0;        // cfg->naive_flatten: accepted, no effect on a planar model (custom.py:1338-1339)
     P.lidar_mode = cfg->lidar_mode;
     P.map_size = cfg->map_size > 0.0 ? cfg->map_size : 40.0;                     // 20 * scale, custom.py:1155,1382

@@ -59,6 +59,7 @@ struct DeviceParams {
     uint64_t seed;
     double dt;
     double rpp;                   // radians per LiDAR point, (2 pi) / n_rays (nidc.py:121), divided once on the host
+    float two_over_rpp, pad_f0;   // 2 / rpp in binary32: seeds the cover-count search (cover_count), nothing else
     // track
     int32_t width, height, words_per_row, fstride;      // fstride = width + 2: cells per row of a field plane (one-pixel ring)
     double px_size_x, px_size_y, origin_x, origin_y, inv_px_x, inv_px_y;
