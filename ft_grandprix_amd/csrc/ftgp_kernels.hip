@@ -559,6 +559,8 @@ __device__ __forceinline__ void lidar_groups(const DeviceParams& P, ScalarParams
     sweep_priority(second_half);
     for (int round = 0; round < (1 << 16); ++round) {          // (bounded: a safety net)
         STAMP(ta);
+        // (a task is drawn when the wave is ready for it, not earlier: drawing the next one before the march -- to hide the LDS round
+        // trip -- reserves work behind a wave that may be on a long group, and cost 6 % on the headline and 12 % on config 2)
         int g = 0;
         if (lane == 0) g = atomicAdd(pool, 1);
         g = __builtin_amdgcn_readfirstlane(g);
