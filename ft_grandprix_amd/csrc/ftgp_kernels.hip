@@ -1437,6 +1437,35 @@ __device__ __forceinline__ double wave_sum_f64(double v)
     return v;
 }
 
+// The same reductions with data-parallel-primitive moves (no LDS round trips; the wave's result comes out of lane 63): the end-of-launch
+// record is on every launch's critical tail, and six sums + a min + a max by __shfl_xor are 96 LDS crossbar trips.
+// one step: every lane receives the value of the lane CTRL names; a lane the step does not address (or whose source lies outside the
+// row) sees the identity: +0 for the sums (old = 0, bound_ctrl), its own value for min / max (old = itself)
+template <int CTRL, int ROW_MASK, int BANK_MASK, bool KEEP_OWN>
+__device__ __forceinline__ double dpp_moved_f64(double v)
+{
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    int mlo, mhi;
+    if (KEEP_OWN) { mlo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, BANK_MASK, false); mhi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, BANK_MASK, false); }
+    else          { mlo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, BANK_MASK, true);   mhi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, BANK_MASK, true); }
+    return __hiloint2double(mhi, mlo);
+}
+template <bool KEEP_OWN, class Op>
+__device__ __forceinline__ double wave_reduce_f64_dpp(double x, Op op)
+{
+    double v = x;
+    v = op(v, dpp_moved_f64<0x111, 0xf, 0xf, KEEP_OWN>(v));      // row_shr:1   -- after the four shifts lane 15 of every row holds the row's result
+    v = op(v, dpp_moved_f64<0x112, 0xf, 0xf, KEEP_OWN>(v));      // row_shr:2
+    v = op(v, dpp_moved_f64<0x114, 0xf, 0xf, KEEP_OWN>(v));      // row_shr:4
+    v = op(v, dpp_moved_f64<0x118, 0xf, 0xf, KEEP_OWN>(v));      // row_shr:8
+    v = op(v, dpp_moved_f64<0x142, 0xa, 0xf, KEEP_OWN>(v));      // row_bcast:15 into rows 1 and 3
+    v = op(v, dpp_moved_f64<0x143, 0xc, 0xf, KEEP_OWN>(v));      // row_bcast:31 into rows 2 and 3
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), FTGP_WAVE - 1), __builtin_amdgcn_readlane(__double2loint(v), FTGP_WAVE - 1));
+}
+__device__ __forceinline__ double wave_total_f64(double x) { return wave_reduce_f64_dpp<false>(x, [](double a, double b) { return a + b; }); }
+__device__ __forceinline__ double wave_least_f64(double x) { return wave_reduce_f64_dpp<true>(x, [](double a, double b) { return fmin(a, b); }); }
+__device__ __forceinline__ double wave_most_f64(double x) { return wave_reduce_f64_dpp<true>(x, [](double a, double b) { return fmax(a, b); }); }
+
 // called by ALL threads of the workgroup, after the state records have gone back to HBM; `scratch`: one int of LDS
 __device__ __forceinline__ void launch_metrics(const DeviceParams& P, const CarCore* cars_lds, const int64_t* steps_lds, int ncars_here, int ci0,
                                                unsigned char* scratch, int slot, int wave)
@@ -1456,9 +1485,8 @@ __device__ __forceinline__ void launch_metrics(const DeviceParams& P, const CarC
             for (int k = 0; k < n; ++k) { v[5] = fmin(v[5], t[k]); v[6] = fmax(v[6], t[k]); }
         }
         #pragma unroll
-        for (int q = 0; q < 5; ++q) v[q] = wave_sum_f64(v[q]);
-        #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) { v[5] = fmin(v[5], shfl_xor_f64(v[5], m)); v[6] = fmax(v[6], shfl_xor_f64(v[6], m)); }
+        for (int q = 0; q < 5; ++q) v[q] = wave_total_f64(v[q]);
+        v[5] = wave_least_f64(v[5]); v[6] = wave_most_f64(v[6]);
         if (lane == 0) {
             // the one lane that publishes also counts: write-through (agent-scope) stores of the record, wait for them, then the ticket
             double* mine = P.wg_metrics + (size_t)blockIdx.x * FTGP_METRIC_DOUBLES;
@@ -1486,9 +1514,8 @@ __device__ __forceinline__ void launch_metrics(const DeviceParams& P, const CarC
             v[6] = fmin(v[6], r[6]); v[7] = fmax(v[7], r[7]);
         }
         #pragma unroll
-        for (int q = 0; q < 6; ++q) v[q] = wave_sum_f64(v[q]);
-        #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) { v[6] = fmin(v[6], shfl_xor_f64(v[6], m)); v[7] = fmax(v[7], shfl_xor_f64(v[7], m)); }
+        for (int q = 0; q < 6; ++q) v[q] = wave_total_f64(v[q]);
+        v[6] = wave_least_f64(v[6]); v[7] = wave_most_f64(v[7]);
         if (lane == 0) {
             #pragma unroll
             for (int q = 0; q < FTGP_METRIC_DOUBLES; ++q) { P.metrics_dev[slot * FTGP_METRIC_DOUBLES + q] = v[q]; P.metrics_host[slot * FTGP_METRIC_DOUBLES + q] = v[q]; }
