@@ -231,6 +231,16 @@ def test_g5_progress_block_on_gpu(product, trace):
     replay_progress_trace(product, trace)
 
 
+def test_lap_time_ring_on_gpu(product, oracle):
+    """More laps than FTGP_MAX_LAP_TIMES: the true count and the ring of the newest 32 (lap time k in slot k % 32), GPU = oracle."""
+    from tests.test_oracle_golden import laps_by_teleport
+    cg, rg, pg = laps_by_teleport(product)
+    co, ro, po = laps_by_teleport(oracle)
+    assert cg == co == 37
+    np.testing.assert_array_equal(rg, ro)
+    np.testing.assert_array_equal(pg, po)
+
+
 def test_g4_accessor_table_on_gpu(product):
     """Rows a5 / a6: lap_completion / absolute_completion of the reference's truth table (fixture G4) read back through
     ftgp_get_progress columns 2-3 and ftgp_get_snapshot columns 7-8."""

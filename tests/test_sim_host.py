@@ -3,6 +3,7 @@
 When the reference checkout is present (/root/reference, never on the GPU box) its OWN nidc / fast / template
 drivers are loaded unmodified through roster strings and driven for a few hundred steps; the closed-loop result must
 agree with the oracle's restated drivers (K5) run on the same worlds."""
+import json
 import os
 import sys
 
@@ -75,3 +76,51 @@ def test_reference_template_driver_runs_unmodified(oracle):
     np.testing.assert_array_equal(sim.env.ctrl(), 0.0)
     np.testing.assert_array_equal(sim.env.steps(), [50])
     sim.close()
+
+
+def test_headless_runner_in_the_shape_of_drive_py(oracle, monkeypatch, capsys, tmp_path):
+    """`python -m ft_grandprix_amd.sim --cars roster.json --track ... --steps N` (drive.py:69-115: roster + track in, loop out): a
+    roster in the reference's layout (template/cars/cars.json), one driver of this package, one module that does not exist (null
+    driver, custom.py:1106-1109); the CPU oracle stands in for the GPU library."""
+    from ft_grandprix_amd import sim as simmod
+    roster = tmp_path / "cars.json"
+    roster.write_text(json.dumps([{"driver": "ft_grandprix_amd.drivers.follow_gap", "name": "gap"},
+                                  {"driver": "file://no/such/driver.py", "name": "ghost"}]))
+    monkeypatch.setattr(capi, "load", lambda: oracle)
+    assert simmod.main(["--cars", str(roster), "--track", "circle", "--steps", "400", "--rays", "90", "--report", "200"]) == 0
+    out = capsys.readouterr().out
+    assert "-- step 200" in out and "-- after 400 steps (1.600 s of simulated time)" in out
+    assert out.count("gap") >= 2 and out.count("ghost") >= 2
+    # the car with a driver has moved along the track, the null driver's car has not
+    lines = [l for l in out.splitlines()[-2:]]
+    assert "gap" in lines[0] and "ghost" in lines[1]                  # ranking: best first
+    # the same roster on the device policy: one launch, same surface
+    assert simmod.main(["--cars", str(roster), "--track", "circle", "--steps", "300", "--device-policy", "nidc"]) == 0
+    assert "-- after 300 steps" in capsys.readouterr().out
+
+
+def test_follow_gap_driver_keeps_a_car_on_the_track(oracle):
+    """The package's own example driver through the plugin surface: 1500 steps on `circle` without leaving the corridor."""
+    t = load_track("circle")
+    sim = Simulator(t, [{"driver": "ft_grandprix_amd.drivers.follow_gap", "name": "gap"}], n_envs=2, n_rays=90, lib=oracle, spawn_mode=1, seed=4)
+    sim.drive(1500)
+    assert not any(vs.off_track for vs in sim.vehicle_states)
+    assert all(vs.absolute_completion() >= 5 for vs in sim.vehicle_states), [vs.absolute_completion() for vs in sim.vehicle_states]
+    sim.close()
+
+
+def test_lap_times_are_a_ring_of_the_newest_32(oracle):
+    """VehicleState.times is unbounded in the reference (custom.py:124,1351-1363); here the newest FTGP_MAX_LAP_TIMES are kept in a
+    ring (lap time k in slot k % 32) beside the true count.  40 forward laps driven through the lap logic alone."""
+    import ctypes as C
+    n_laps, per_lap = 40, 5
+    closest = np.array([(5 + (0, 25, 50, 75, 99)[k % per_lap]) % 100 for k in range(n_laps * per_lap + 1)], dtype=np.int32)   # completion 0, 25, 50, 75, 99, 0, ...: 5 steps per lap
+    off = np.zeros(len(closest), dtype=np.uint8)
+    out = np.zeros((len(closest), 6), dtype=np.int32)
+    ring = np.zeros(capi.MAX_LAP_TIMES)
+    assert oracle.dll.oracle_progress_trace(5, 1000, 0.004, len(closest), closest.ctypes.data, off.ctypes.data, out.ctypes.data, ring.ctypes.data) == 0
+    count = int(out[-1, 3])
+    assert count == n_laps and int(out[-1, 0]) == n_laps                  # a car starts with good_start set (custom.py:113): every crossing appends
+    times = capi.lap_time_list(count, ring)
+    assert len(times) == capi.MAX_LAP_TIMES and all(abs(t - per_lap * 0.004) < 1e-12 for t in times)
+    assert capi.lap_time_list(3, ring) == [ring[0], ring[1], ring[2]]
