@@ -12,6 +12,7 @@
 #include <utility>
 #include <vector>
 
+#include <hip/hip_ext.h>
 #include "ftgp_kernels.hip"
 
 namespace {
@@ -73,9 +74,10 @@ struct FtgpEnv {
     hipStream_t stream = nullptr, side = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop[2] = { nullptr, nullptr }, ev_metrics = nullptr, ev_gather = nullptr;      // ev_stop: one per metrics slot
     bool timed = false;
+    bool ext_launch = true;      // FTGP_LAUNCH_PLAIN=1 switches it off (tools/launch_host.sh)
     // device buffers
     uint16_t* d_field = nullptr; uint32_t* d_bits = nullptr; uint32_t* d_nearbits = nullptr;
-    double* d_path = nullptr; double* d_spawn = nullptr; float* d_ray = nullptr; float* d_cover = nullptr; void* d_veh = nullptr; DeviceParams* d_params = nullptr;
+    double* d_path = nullptr; double* d_spawn = nullptr; float* d_ray = nullptr; float* d_cover = nullptr; void* d_veh = nullptr; unsigned char* d_stage = nullptr; DeviceParams* d_params = nullptr;
     CarState* d_cars = nullptr; float* d_ranges = nullptr; int64_t* d_steps = nullptr;
     uint8_t* d_env_mask = nullptr; uint8_t* d_car_mask = nullptr; double* d_ctrl = nullptr; double* d_pose = nullptr;
     double* d_metrics = nullptr; double* d_gather = nullptr; double* d_wg_metrics = nullptr; unsigned int* d_wg_ticket = nullptr;
@@ -216,6 +218,10 @@ int lds_layout(DeviceParams& P, int cpb, int wpb)
     return o;
 }
 
+// Waiting for an event of a launch is a blocked wait.  Polling hipEventQuery instead was measured (tools/launch_host.sh, round 4): 7 us
+// SLOWER per launch -- every query takes the runtime's locks and walks the stream's command list.
+hipError_t wait_event(const FtgpEnv*, hipEvent_t ev) { return hipEventSynchronize(ev); }
+
 int launch_steps(FtgpEnv* e, int policy, int n_steps)
 {
     e->rows_valid = false;
@@ -233,25 +239,29 @@ int launch_steps(FtgpEnv* e, int policy, int n_steps)
     if (n_steps > 0 && e->gather_open && e->gather_slot == slot) {
         if (e->comm) HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_gather, 0));
         else if (!e->gather_held) {
-            HIP_TRY(hipEventSynchronize(e->gather_event));
+            HIP_TRY(wait_event(e, e->gather_event));
             memcpy(e->held, e->h_metrics + (size_t)slot * FTGP_METRIC_DOUBLES, sizeof e->held);
             e->gather_held = true;
         }
     }
-    HIP_TRY(hipEventRecord(e->ev_start, e->stream));
+    // The launch's two events ride on the kernel's own dispatch packet (hipExtLaunchKernelGGL): no marker packet before and after it,
+    // and their difference is the kernel's time alone.  FTGP_LAUNCH_PLAIN=1: hipEventRecord on either side instead.
+    const bool ext = e->ext_launch && n_steps > 0;
+    if (!ext) HIP_TRY(hipEventRecord(e->ev_start, e->stream));
     if (n_steps > 0) {
         const dim3 grid(blocks), block(e->P.waves_per_block * FTGP_WAVE);
-        const size_t lds = (size_t)e->P.lds_bytes;
+        const uint32_t lds = (uint32_t)e->P.lds_bytes;
         const bool fake = e->P.lidar_mode == FTGP_LIDAR_FAKELIDAR;
-        if (e->multi) { if (fake) hipLaunchKernelGGL((ftgp_step_kernel<true, true>), grid, block, lds, e->stream, e->d_params, policy, n_steps, slot);
-                        else      hipLaunchKernelGGL((ftgp_step_kernel<true, false>), grid, block, lds, e->stream, e->d_params, policy, n_steps, slot); }
-        else          { if (fake) hipLaunchKernelGGL((ftgp_step_kernel<false, true>), grid, block, lds, e->stream, e->d_params, policy, n_steps, slot);
-                        else      hipLaunchKernelGGL((ftgp_step_kernel<false, false>), grid, block, lds, e->stream, e->d_params, policy, n_steps, slot); }
+        hipEvent_t ev0 = ext ? e->ev_start : nullptr, ev1 = ext ? e->ev_stop[slot] : nullptr;
+        if (e->multi) { if (fake) hipExtLaunchKernelGGL((ftgp_step_kernel<true, true>), grid, block, lds, e->stream, ev0, ev1, 0, e->d_params, policy, n_steps, slot);
+                        else      hipExtLaunchKernelGGL((ftgp_step_kernel<true, false>), grid, block, lds, e->stream, ev0, ev1, 0, e->d_params, policy, n_steps, slot); }
+        else          { if (fake) hipExtLaunchKernelGGL((ftgp_step_kernel<false, true>), grid, block, lds, e->stream, ev0, ev1, 0, e->d_params, policy, n_steps, slot);
+                        else      hipExtLaunchKernelGGL((ftgp_step_kernel<false, false>), grid, block, lds, e->stream, ev0, ev1, 0, e->d_params, policy, n_steps, slot); }
         HIP_TRY(hipGetLastError());
         e->cur_slot = slot;
         e->launch_metrics_valid = e->d_wg_metrics != nullptr;
     }
-    HIP_TRY(hipEventRecord(e->ev_stop[e->cur_slot], e->stream));
+    if (!ext) HIP_TRY(hipEventRecord(e->ev_stop[e->cur_slot], e->stream));
     e->timed = true;
     return 0;
 }
@@ -352,7 +362,7 @@ int ftgp_destroy(FtgpEnv* e)
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->side) (void)hipStreamSynchronize(e->side);
     if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
-    void* bufs[] = { e->d_field, e->d_bits, e->d_nearbits, e->d_cover, e->d_params, e->d_veh, e->d_path, e->d_spawn, e->d_ray, e->d_cars, e->d_ranges,
+    void* bufs[] = { e->d_field, e->d_bits, e->d_nearbits, e->d_cover, e->d_stage, e->d_params, e->d_veh, e->d_path, e->d_spawn, e->d_ray, e->d_cars, e->d_ranges,
                      e->d_steps, e->d_env_mask, e->d_car_mask, e->d_ctrl, e->d_pose, e->d_metrics, e->d_gather, e->d_prog, e->d_core, e->d_wg_metrics, e->d_wg_ticket,
                      e->d_edt, e->d_fan };
     for (void* b : bufs) if (b) (void)hipFree(b);
@@ -402,6 +412,7 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
     if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(FTGP_ERR_ARG, "device_id out of range%s");
 
     FtgpEnv* e = new FtgpEnv();
+    e->ext_launch = !getenv("FTGP_LAUNCH_PLAIN");
     e->cfg = *cfg;
     e->device = cfg->device_id;
 #define CREATE_TRY(expr)                                                                           \
@@ -674,7 +685,21 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
     CREATE_TRY(hipMemsetAsync(e->d_steps, 0, sizeof(int64_t) * (size_t)P.n_envs, e->stream));
     P.bits = e->d_bits; P.nearbits = e->d_nearbits; P.path = e->d_path; P.spawn = e->d_spawn;
     P.ray_dir = e->d_ray; P.cars = e->d_cars; P.ranges = e->d_ranges; P.steps = e->d_steps;
-    {   // device image of the parameter block (padded to 16 B for the LDS staging copy)
+    {   // the staging image: the LDS bytes [off_params, off_cars) as every workgroup wants them, then both drivers' cover tables
+        const size_t head = (size_t)(P.off_cars - P.off_params), cover = (size_t)(P.lds_bytes - P.off_cover);
+        std::vector<unsigned char> simg(head + 2 * cover, 0);
+        CREATE_TRY(hipMalloc(&e->d_stage, simg.size()));
+        P.stage_img = e->d_stage; P.stage_cover = (int32_t)cover;
+        memcpy(simg.data() + (P.off_params - P.off_params), &P, offsetof(DeviceParams, veh));
+        CREATE_TRY(hipMemcpy(simg.data() + (P.off_veh - P.off_params), e->d_veh, (size_t)pad16(sizeof(VehLds)), hipMemcpyDeviceToHost));
+        memcpy(simg.data() + (P.off_path - P.off_params), t.path, sizeof(double) * 2 * FTGP_PATH_POINTS);
+        memcpy(simg.data() + (P.off_ray - P.off_params), ray.data(), sizeof(float) * 2 * (size_t)cfg->n_rays);
+        const size_t stride = (size_t)P.cover_kmax + 1;
+        CREATE_TRY(hipMemcpy(simg.data() + head, e->d_cover, std::min(cover, sizeof(float) * stride), hipMemcpyDeviceToHost));
+        CREATE_TRY(hipMemcpy(simg.data() + head + cover, e->d_cover + stride, std::min(cover, sizeof(float) * stride), hipMemcpyDeviceToHost));
+        CREATE_TRY(hipMemcpy(e->d_stage, simg.data(), simg.size(), hipMemcpyHostToDevice));
+    }
+    {   // device image of the parameter block
         std::vector<unsigned char> pimg((size_t)pad16(sizeof(DeviceParams)), 0);
         memcpy(pimg.data(), &P, sizeof(DeviceParams));
         CREATE_TRY(hipMalloc(&e->d_params, pimg.size()));
@@ -967,7 +992,7 @@ int ftgp_metrics_allgather_end(FtgpEnv* e, double* out)
     if (!e || !out) return fail(FTGP_ERR_ARG, "null argument%s");
     if (!e->gather_open) return fail(FTGP_ERR_STATE, "ftgp_metrics_allgather_end without _begin%s");
     HIP_TRY(hipSetDevice(e->device));
-    if (!e->gather_held) HIP_TRY(hipEventSynchronize(e->gather_event));      // this exchange only: a later launch on the compute stream is not waited for
+    if (!e->gather_held) HIP_TRY(wait_event(e, e->gather_event));      // this exchange only: a later launch on the compute stream is not waited for
     e->gather_open = false;
     if (e->comm) memcpy(out, e->h_gather, sizeof(double) * FTGP_METRIC_DOUBLES * (size_t)e->world);
     else if (e->gather_held) memcpy(out, e->held, sizeof e->held);
@@ -1025,7 +1050,7 @@ int ftgp_last_kernel_ms(FtgpEnv* e, float* ms)
     if (!e || !ms) return fail(FTGP_ERR_ARG, "null argument%s");
     if (!e->timed) return fail(FTGP_ERR_STATE, "no step/rollout has been launched yet%s");
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipEventSynchronize(e->ev_stop[e->cur_slot]));
+    HIP_TRY(wait_event(e, e->ev_stop[e->cur_slot]));
     HIP_TRY(hipEventElapsedTime(ms, e->ev_start, e->ev_stop[e->cur_slot]));
     return 0;
 }

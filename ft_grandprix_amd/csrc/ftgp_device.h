@@ -107,6 +107,9 @@ struct DeviceParams {
     alignas(16) int32_t sector_tab[FTGP_SECTORS][4];     // ftgp_sector_entry() of every sector (staged into LDS with the head of the block)
     FtgpVehicle veh;              // host-side copy (the step kernel reads the LDS image VehLds; from here on nothing is staged into LDS)
     double wheel_load[4];
+    const unsigned char* stage_img;      // what every workgroup stages at the start of a launch, in ONE pass: the image of the LDS bytes [off_params, off_cars)
+                                  // (head of this block | VehLds | path | fan), then the cover tables of nidc and of fast, stage_cover bytes each
+    int32_t stage_cover, reserved3;
     int32_t group_order[FTGP_MAX_GROUPS];      // the tasks of a car by expected march length, longest first (rays along the car's axis look down the
                                   // track, sideways rays hit the corridor wall at once): first ray | kind << 16, kind 0 = one group of 64
                                   // consecutive rays, 1 = that group and the opposite one (first ray + n/2), 2 = the short ends of both halves in

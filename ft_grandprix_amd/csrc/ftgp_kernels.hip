@@ -1032,6 +1032,16 @@ __device__ __forceinline__ void mate_masks(const LidarFrame* frames, const PairC
     }
 }
 
+// One exchange of K3's argmin inside a quad of lanes: every lane sees the (distance, index) of the lane QUAD_PERM names and keeps the better pair
+template <int QUAD_PERM>
+__device__ __forceinline__ void quad_argmin_step(double& best, int& idx)
+{
+    const int lo = __double2loint(best), hi = __double2hiint(best);
+    const double ob = __hiloint2double(__builtin_amdgcn_update_dpp(hi, hi, QUAD_PERM, 0xf, 0xf, false), __builtin_amdgcn_update_dpp(lo, lo, QUAD_PERM, 0xf, 0xf, false));
+    const int oi = __builtin_amdgcn_update_dpp(idx, idx, QUAD_PERM, 0xf, 0xf, false);
+    if (ob < best || (ob == best && oi < idx)) { best = ob; idx = oi; }
+}
+
 // K1 + K3 for every car of the workgroup by ONE wave, four lanes per car (lane = 4 * car + r).
 //   K1  lane r evaluates wheel r (fl, fr, bl, br), then wall-contact circle r (r < 3), then wheel softener r (bubble_wrap);
 //       the force terms go to an LDS staging row and lane 0 of the car adds them up in the specification's order
@@ -1166,12 +1176,10 @@ __device__ __forceinline__ void dynamics_lanes(const DeviceParams& P, const Lds&
         const double d = dx * dx + dy * dy;
         if (d < best) { best = d; idx = i; }
     }
-    #pragma unroll
-    for (int m = 1; m <= 2; m <<= 1) {       // the lower index wins ties; a NaN never wins (the oracle's `d < best` is false for it too)
-        const double ob = shfl_xor_f64(best, m);
-        const int oi = __shfl_xor(idx, m, FTGP_WAVE);
-        if (ob < best || (ob == best && oi < idx)) { best = ob; idx = oi; }
-    }
+    // the car's four lanes: exchanges inside the quad by DPP (quad_perm [1,0,3,2], then [2,3,0,1]), no LDS crossbar trip.
+    // The lower index wins ties; a NaN never wins (the oracle's `d < best` is false for it too)
+    quad_argmin_step<0xB1>(best, idx);
+    quad_argmin_step<0x4E>(best, idx);
     if (on && r == 0) {
         Race rc; race_load(rc, st);
         progress_update(P, rc, L.steps[c], idx, best, P.cars[ci0 + c].times);
@@ -1468,7 +1476,7 @@ __device__ __forceinline__ double wave_most_f64(double x) { return wave_reduce_f
 
 // called by ALL threads of the workgroup, after the state records have gone back to HBM; `scratch`: one int of LDS
 __device__ __forceinline__ void launch_metrics(const DeviceParams& P, const CarCore* cars_lds, const int64_t* steps_lds, int ncars_here, int ci0,
-                                               unsigned char* scratch, int slot, int wave)
+                                               unsigned char* scratch, double* partial /* [waves][FTGP_METRIC_DOUBLES] of LDS */, int slot, int wave)
 {
     int* last_flag = reinterpret_cast<int*>(scratch);
     const int lane = lane_id();
@@ -1505,13 +1513,34 @@ __device__ __forceinline__ void launch_metrics(const DeviceParams& P, const CarC
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
-    if (wave == 0) {
+    // every thread of the last workgroup takes records (one thread per workgroup of the grid: the loads of a record are in flight together and
+    // the whole read costs one memory latency), each wave reduces its lanes by DPP, wave 0 reduces the waves' results
+    static_assert(sizeof(double) * 2 * FTGP_PATH_POINTS >= 16 * FTGP_METRIC_DOUBLES * sizeof(double), "the centre line's LDS bytes hold the waves' partial records");
+    const int nwaves = (int)(blockDim.x >> 6);
+    {
         double v[FTGP_METRIC_DOUBLES] = { 0, 0, 0, 0, 0, 0, INFINITY, -INFINITY };
-        for (unsigned int b = lane; b < gridDim.x; b += FTGP_WAVE) {
+        for (unsigned int b = (unsigned int)(wave * FTGP_WAVE + lane); b < gridDim.x; b += blockDim.x) {      // (threadIdx.x itself would be one more register held from the kernel's first instruction to here)
             const double* r = P.wg_metrics + (size_t)b * FTGP_METRIC_DOUBLES;
             #pragma unroll
             for (int q = 0; q < 6; ++q) v[q] += r[q];
             v[6] = fmin(v[6], r[6]); v[7] = fmax(v[7], r[7]);
+        }
+        if ((unsigned int)wave * FTGP_WAVE < gridDim.x) {                 // waves without a record have nothing to add (workgroup-uniform per wave)
+            #pragma unroll
+            for (int q = 0; q < 6; ++q) v[q] = wave_total_f64(v[q]);
+            v[6] = wave_least_f64(v[6]); v[7] = wave_most_f64(v[7]);
+        }
+        if (lane == 0) {
+            #pragma unroll
+            for (int q = 0; q < FTGP_METRIC_DOUBLES; ++q) partial[wave * FTGP_METRIC_DOUBLES + q] = v[q];
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        double v[FTGP_METRIC_DOUBLES] = { 0, 0, 0, 0, 0, 0, INFINITY, -INFINITY };
+        if (lane < nwaves) {
+            #pragma unroll
+            for (int q = 0; q < FTGP_METRIC_DOUBLES; ++q) v[q] = partial[lane * FTGP_METRIC_DOUBLES + q];
         }
         #pragma unroll
         for (int q = 0; q < 6; ++q) v[q] = wave_total_f64(v[q]);
@@ -1560,13 +1589,21 @@ __global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(cons
         ftgp_wg_times[blockIdx.x][2] = hw; ftgp_wg_times[blockIdx.x][3] = xcc;
     }
 #endif
-    // the parameter block itself goes to LDS: later reads come from there, not from ~70 pinned SGPRs
-    stage16(lds + Pg->off_params, Pg, Pg->off_veh - Pg->off_params);
-    stage16(lds + Pg->off_veh, Pg->veh_dev, Pg->off_path - Pg->off_veh);
-    stage16(lds + Pg->off_path, Pg->path, Pg->off_ray - Pg->off_path);
-    stage16(lds + Pg->off_ray, Pg->ray_dir, Pg->off_cars - Pg->off_ray);
-    if (policy == FTGP_POLICY_NIDC || policy == FTGP_POLICY_FAST)
-        stage16(lds + Pg->off_cover, Pg->cover_thr + (policy == FTGP_POLICY_FAST ? Pg->cover_kmax + 1 : 0), Pg->lds_bytes - Pg->off_cover);
+    // The parameter block itself goes to LDS (later reads come from there, not from ~70 pinned SGPRs), with the vehicle constants, the centre
+    // line, the fan and the driver's cover table: ONE image in HBM laid out as the LDS is (ftgp_create), so that a thread's loads are all in
+    // flight together -- the launch pays one memory latency here, not one per table.
+    {
+        const int head = Pg->off_cars - Pg->off_params, cover = (policy == FTGP_POLICY_NIDC || policy == FTGP_POLICY_FAST) ? Pg->stage_cover : 0;
+        const uint4* img = reinterpret_cast<const uint4*>(Pg->stage_img);
+        const uint4* cov = img + ((head + (policy == FTGP_POLICY_FAST ? Pg->stage_cover : 0)) >> 4);
+        uint4* d_head = reinterpret_cast<uint4*>(lds + Pg->off_params);
+        uint4* d_cov = reinterpret_cast<uint4*>(lds + Pg->off_cover);
+        const int nh = head >> 4, n = nh + (cover >> 4);
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            if (i < nh) d_head[i] = img[i];
+            else d_cov[i - nh] = cov[i - nh];
+        }
+    }
     if (threadIdx.x < 8) reinterpret_cast<int*>(lds + Pg->off_pool)[threadIdx.x] = 0;
     __syncthreads();
     const LdsOffsets off = lds_offsets(P0);
@@ -1583,17 +1620,21 @@ __global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(cons
     const DeviceParams& P = P0;
     const Lds L = lds_view(off, lds);
     const int R = P.n_rays, eighth = P.eighth, win_floats = P.win_floats;
+    if (need_scan) {     // the scan of the previous launch is what the first driver call sees: buffer 1 = parity of step -1.  All waves fetch it,
+                         // a thread's loads (one per car) in flight together; the first driver call is on the launch's critical path
+        const int nwin = R - 2 * eighth;
+        for (int j = (int)threadIdx.x; j < nwin; j += (int)blockDim.x) {
+            #pragma unroll 8
+            for (int c = 0; c < ncars_here; ++c)
+                L.scan[(cpb + c) * win_floats + scan_window_first(eighth) + j] = P.ranges[(size_t)(ci0 + c) * P.ranges_stride + eighth + j];
+        }
+        if ((int)threadIdx.x < ncars_here) L.scan[(cpb + (int)threadIdx.x) * win_floats + win_floats - 1] = P.ranges[(size_t)(ci0 + (int)threadIdx.x) * P.ranges_stride];
+    }
     for (int c = wave; c < ncars_here; c += nwaves) {
         const int ci = ci0 + c;
         if (lane < (int)(sizeof(CarCore) / 4))
             reinterpret_cast<uint32_t*>(L.cars + c)[lane] = reinterpret_cast<const uint32_t*>(static_cast<const CarCore*>(&P.cars[ci]))[lane];
         if (lane == 0) L.steps[c] = P.steps[ci / P.cars_per_env];
-        if (need_scan) {     // the scan of the previous launch is what the first driver call sees: buffer 1 = parity of step -1
-            const float* my_ranges = P.ranges + (size_t)ci * P.ranges_stride;
-            float* row = L.scan + (cpb + c) * win_floats;
-            if (lane == 0) row[win_floats - 1] = my_ranges[0];
-            for (int j = eighth + lane; j < R - eighth; j += FTGP_WAVE) row[scan_window_first(eighth) + j - eighth] = my_ranges[j];
-        }
         wave_lds_sync();
         if (lane == 0 && !frame_write(P, L.veh->v, L.cars + c, L.frame + c, c)) atomicOr(L.pool + 4, 1);
     }
@@ -1700,9 +1741,9 @@ __global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(cons
             reinterpret_cast<uint32_t*>(static_cast<CarCore*>(&P.cars[ci]))[lane_here()] = reinterpret_cast<const uint32_t*>(L.cars + c)[lane_here()];
         if (lane_here() == 0 && ci % P.cars_per_env == 0) P.steps[ci / P.cars_per_env] = L.steps[c];
     }
-    if (P.wg_metrics) {                  // the scan windows are dead now: their first bytes serve as the reduction scratch
+    if (P.wg_metrics) {                  // the scan windows and the centre line are dead now: the reduction's scratch
         __syncthreads();
-        launch_metrics(P, L.cars, L.steps, ncars_here, ci0, lds + P.off_scan, metrics_slot, wave);
+        launch_metrics(P, L.cars, L.steps, ncars_here, ci0, lds + P.off_scan, reinterpret_cast<double*>(lds + P.off_path), metrics_slot, wave);
     }
 #ifdef FTGP_WG_TIMES
     __syncthreads();
