@@ -786,7 +786,7 @@ __device__ __forceinline__ void progress_update(const DeviceParams& P, Race& s, 
         }
     }
     if (s.laps >= P.lap_target) {                         // custom.py:1367-1370; the step of the first time orders the winners (custom.py:1368-1369)
-        if (!s.finished) s.finish_step = (int32_t)steps;
+        if (!s.finished) s.finish_step = steps > 0x7fffffffll ? 0x7fffffff : (int32_t)steps;      // the progress row is int32: saturates after 2^31 - 1 steps
         s.finished = 1;
     }
     s.completion = completion;

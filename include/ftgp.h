@@ -58,7 +58,8 @@ extern "C" {
 #define FTGP_SNAPSHOT_DOUBLES 10 /* laps, vel[3], yaw, pitch, roll, lap_completion, absolute_completion, time */
 #define FTGP_POSE_DOUBLES     13 /* qpos[7] = x y z qw qx qy qz ; qvel[6] = vx vy vz wx wy wz */
 #define FTGP_PROGRESS_INTS    10 /* laps, completion, lap_completion, absolute_completion, finished, off_track, start, good_start, delta,
-                                    finish_step: the env step at which `finished` was set (custom.py:1367-1370), -1 while racing */
+                                    finish_step: the env step at which `finished` was set (custom.py:1367-1370), -1 while racing;
+                                    the row is int32 while steps are int64: saturates at 2^31 - 1 (99 days of simulated time) */
 #define FTGP_METRIC_DOUBLES    8 /* steps, n_cars, sum_laps, sum_abs_completion, n_finished, n_off_track, min_lap_time, max_lap_time */
 
 /*

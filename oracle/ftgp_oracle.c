@@ -571,7 +571,7 @@ static void progress_car(OracleEnv *e, int ci)
         }
     }
     if (a->laps >= e->cfg.lap_target) {              /* custom.py:1367-1370: winners[id] = len(winners) + 1 the first time */
-        if (!a->finished) a->finish_step = (int32_t)steps;
+        if (!a->finished) a->finish_step = steps > 0x7fffffffll ? 0x7fffffff : (int32_t)steps;   /* int32 row: saturates */
         if (e->place[ci] == 0) e->place[ci] = ++e->n_winners[env];     /* kept the reference's way: a dict filled inside the per-car loop */
         a->finished = 1;
     }
