@@ -393,8 +393,9 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
     if (t.width > 8192 || t.height > 8192) return fail(FTGP_ERR_ARG, "images above 8192 pixels are not supported%s");
     // Direction sectors of the box field: more slope slices mean fewer march iterations and a larger field.  A large batch is bound by
     // throughput and by what of the field its cars keep in the 4-MiB L2s (16 sectors: 32 bytes per pixel); a small one by the latency of
-    // its longest rays (64 sectors).  Measured on both: profiles/round4/ab_sectors.log.  Results do not depend on the choice.
-    int n_sectors = (long)cfg->n_envs * cfg->cars_per_env >= 2048 ? 16 : 64;
+    // its longest rays (64 sectors); 16384 cars (config 5) do best with 8.  Measured: profiles/round4/ab_sectors.log.  Results do not depend on the choice.
+    const long cars_total = (long)cfg->n_envs * cfg->cars_per_env;
+    int n_sectors = cars_total >= 8192 ? 8 : cars_total >= 2048 ? 16 : 64;
     if (const char* sv = getenv("FTGP_SECTORS_RT")) { const int c = atoi(sv); if (c == 8 || c == 16 || c == 32 || c == 64) n_sectors = c; }
     // the march addresses the field with a 32-bit byte offset
     if ((uint64_t)ftgp_plane256(t.width, t.height) * 256u * (uint64_t)n_sectors > 0xFFFFFFFFull)

@@ -459,7 +459,7 @@ __device__ __forceinline__ void lidar_pool(const DeviceParams& P, ScalarParams G
 // instruction (profiles/round4/salu_cost.log) -- and the compiler's loop spends 13 scalar-side instructions per iteration on mask
 // bookkeeping.  Here a lane leaves the loop by dropping out of exec (v_cmpx on "the cell's entry is a box", i.e. kx != 0), so the
 // body needs no live mask, finished rays hold their cell and crossing time for free (and burn no vector lanes), and the loop
-// closes with one branch on exec: 20 vector + 4 scalar-side instructions per iteration, + the near-boundary path.
+// closes with one branch on exec: 20 vector + 3 scalar-side instructions per iteration, + the near-boundary path.
 // In: exec = the lanes that hold a ray; ix, iy = (mirrored) cell, s = crossing time into it (0 at the origin).
 // Out: w = entry of the terminal cell (0 = wall, FTGP_FIELD_OUT = ring), s = crossing time into it, exec as on entry.
 // The arithmetic is ftgp_ray_step / ftgp_ray_fix / ftgp_ray_commit of ftgp_march.h, instruction for instruction.
@@ -469,16 +469,19 @@ __device__ __forceinline__ void march_all(int& ix, int& iy, float& s, uint32_t& 
     int a, b, c, d, e, f, h, i;
     uint64_t stepx, sv, sq, ex0;
     asm volatile(
-        "s_mov_b64 %[ex0], exec\n"
+        "s_mov_b64 %[ex0], exec\n\t"
+        // the look-up of the cell a ray stands on: entry offset = ftgp_ray_offset(), far corner of its box, "is it a box at all"
+#define FTGP_MARCH_LOOKUP \
+        "v_mad_i32_i24 %[a], %[iy], %[ay], %[offC]\n\t" \
+        "v_mad_i32_i24 %[a], %[ix], %[ax], %[a]\n\t" \
+        "global_load_ushort %[w], %[a], %[field]\n\t" \
+        "s_waitcnt vmcnt(0)\n\t" \
+        "v_add_u32_sdwa %[c], %[ix], %[w] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"     /* xe = ix + kx */ \
+        "v_add_u32_sdwa %[d], %[iy], %[w] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t"     /* ye = iy + ky */ \
+        "v_cmpx_ne_u32_e32 vcc, %[c], %[ix]\n\t"                         /* kx == 0: wall or ring cell -- the lane is done */
+        FTGP_MARCH_LOOKUP
+        "s_cbranch_execz L_march_done_%=\n"
         "L_march_loop_%=:\n\t"
-        "v_mad_i32_i24 %[a], %[iy], %[ay], %[offC]\n\t"
-        "v_mad_i32_i24 %[a], %[ix], %[ax], %[a]\n\t"
-        "global_load_ushort %[w], %[a], %[field]\n\t"
-        "s_waitcnt vmcnt(0)\n\t"
-        "v_add_u32_sdwa %[c], %[ix], %[w] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"     // xe = ix + kx
-        "v_add_u32_sdwa %[d], %[iy], %[w] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t"     // ye = iy + ky
-        "v_cmpx_ne_u32_e32 vcc, %[c], %[ix]\n\t"                         // kx == 0: wall or ring cell -- the lane is done
-        "s_cbranch_execz L_march_done_%=\n\t"
         "v_cvt_f32_i32_e32 %[a], %[c]\n\t"
         "v_cvt_f32_i32_e32 %[b], %[d]\n\t"
         "v_sub_f32_e32 %[a], %[a], %[pum]\n\t"
@@ -498,7 +501,9 @@ __device__ __forceinline__ void march_all(int& ix, int& iy, float& s, uint32_t& 
         "L_march_commit_%=:\n\t"
         "v_cndmask_b32_e64 %[ix], %[h], %[c], %[stepx]\n\t"
         "v_cndmask_b32_e64 %[iy], %[d], %[h], %[stepx]\n\t"
-        "s_branch L_march_loop_%=\n"
+        FTGP_MARCH_LOOKUP                                                 // (the loop is rotated: its one taken branch is the one that closes it)
+        "s_cbranch_execnz L_march_loop_%=\n\t"
+        "s_branch L_march_done_%=\n"
         "L_march_fix_%=:\n\t"                                            // ftgp_ray_fix() for the lanes in vcc
         "s_and_saveexec_b64 %[sv], vcc\n\t"
         "v_cndmask_b32_e64 %[a], %[pum], %[pvm], %[stepx]\n\t"           // transverse origin ...
