@@ -125,6 +125,7 @@ int main(int argc, char** argv)
     if (getenv("HIST")) {          // iterations per ray, and per group of 64 consecutive rays (= the slowest ray of the group): lidar_groups
         std::vector<long> hr(64, 0), hg(64, 0); long sum_g = 0, ng = 0, sum_r = 0;
         std::vector<long> by_index(R, 0);
+        long alt_sum[4] = { 0, 0, 0, 0 };
         for (int c = 0; c < n_cars; ++c) {
             const double* p = &pose[(size_t)c * 4];
             const double ch = 1.0 - 2.0 * (p[3] * p[3]), sh = 2.0 * (p[2] * p[3]);
@@ -132,6 +133,7 @@ int main(int argc, char** argv)
             const float u0 = (float)((lcx - ph[3]) * (1.0 / ph[1])), v0 = (float)((ph[4] - lcy) * (1.0 / ph[2]));
             const float chf = (float)ch, shf = (float)sh;
             int gmax = 0;
+            std::vector<int> cnt_of(R); std::vector<float> range_of(R);
             for (int j = 0; j < R; ++j) {
                 const float dxw = fmaf(chf, bx[j], -(shf * by[j])), dyw = fmaf(shf, bx[j], chf * by[j]);
                 const float du = dxw * isx, dv = -(dyw * isy);
@@ -143,11 +145,27 @@ int main(int argc, char** argv)
                     ftgp_ray_commit(r, st, near ? ftgp_ray_fix(r, st) : st.t);
                     if (!st.live) break;
                 }
+                cnt_of[j] = n; range_of[j] = fabsf(r.s);
                 hr[std::min(n, 63)]++; sum_r += n; by_index[j] += n;
                 gmax = std::max(gmax, n);
                 if ((j & 63) == 63 || j == R - 1) { hg[std::min(gmax, 63)]++; sum_g += gmax; ++ng; gmax = 0; }
             }
+            // what-if: groups of 64 formed from the car's rays in another order -- by the true count (the bound), by the range (what the
+            // previous step's scan would offer), by the range quantised to 1/4 unit with the index as tie-break (keeps neighbours together)
+            auto grouped = [&](auto key) {
+                std::vector<int> idx(R); for (int j = 0; j < R; ++j) idx[j] = j;
+                std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return key(a) > key(b); });
+                long sum = 0; int m = 0;
+                for (int k = 0; k < R; ++k) { m = std::max(m, cnt_of[idx[k]]); if ((k & 63) == 63 || k == R - 1) { sum += m; m = 0; } }
+                return sum;
+            };
+            alt_sum[0] += grouped([&](int j) { return (double)cnt_of[j]; });
+            alt_sum[1] += grouped([&](int j) { return (double)range_of[j]; });
+            alt_sum[2] += grouped([&](int j) { return floor((double)range_of[j] * 4.0); });
+            alt_sum[3] += grouped([&](int j) { return floor((double)range_of[j] * 1.0); });
         }
+        printf("what-if, wave-iterations per car-step with groups of 64 after sorting a car's rays: by true count %.1f, by range %.1f, by range in 1/4-unit bins %.1f, in 1-unit bins %.1f\n",
+               (double)alt_sum[0] / n_cars, (double)alt_sum[1] / n_cars, (double)alt_sum[2] / n_cars, (double)alt_sum[3] / n_cars);
         printf("iterations per ray: mean %.2f; per group of 64: mean %.2f (x %.1f groups per car = %.1f wave-iterations per car-step)\n", (double)sum_r / ((double)n_cars * R), (double)sum_g / ng, (double)ng / n_cars, (double)sum_g / n_cars);
         printf("  n    rays%%  groups%%\n");
         for (int n = 1; n < 64; ++n) if (hr[n] || hg[n]) printf("%3d  %6.2f  %6.2f\n", n, 100.0 * hr[n] / ((double)n_cars * R), 100.0 * hg[n] / ng);
