@@ -26,8 +26,9 @@ METRIC_DOUBLES = 8
 POLICY_HOST, POLICY_LOBOTOMY, POLICY_NIDC, POLICY_FAST, POLICY_RANDOM = 0, 1, 2, 3, 4
 LIDAR_RANGEFINDER, LIDAR_FAKELIDAR = 0, 1
 LIDAR_BY_NAME = {"rangefinder": LIDAR_RANGEFINDER, "fakelidar": LIDAR_FAKELIDAR}
+POLICY_PER_CAR = 5
 POLICY_BY_NAME = {"host": POLICY_HOST, "lobotomy": POLICY_LOBOTOMY, "nidc": POLICY_NIDC,
-                  "fast": POLICY_FAST, "random": POLICY_RANDOM}
+                  "fast": POLICY_FAST, "random": POLICY_RANDOM, "per_car": POLICY_PER_CAR}
 
 PROGRESS_FIELDS = ("laps", "completion", "lap_completion", "absolute_completion", "finished",
                    "off_track", "start", "good_start", "delta", "finish_step")
@@ -71,7 +72,7 @@ class FtgpConfig(C.Structure):
 # every symbol include/ftgp.h declares (checked by tests/test_capi.py)
 API_SYMBOLS = (
     "default_vehicle", "tricycle_vehicle", "last_error", "device_count", "create", "destroy", "reset", "set_ctrl", "step",
-    "rollout", "get_lidar", "get_snapshot", "get_pose", "get_progress", "get_winners", "get_lap_times", "get_ctrl",
+    "rollout", "set_car_policies", "get_lidar", "get_snapshot", "get_pose", "get_progress", "get_winners", "get_lap_times", "get_ctrl",
     "get_steps", "set_pose", "policy_eval", "eval_progress", "metrics_local", "comm_unique_id", "comm_init", "metrics_allgather",
     "metrics_allgather_begin", "metrics_allgather_end", "get_distance_field",
     "last_kernel_ms", "kernel_name", "fakelidar", "selftest",
@@ -118,6 +119,7 @@ class CLib:
             "set_ctrl": (i32, [vp, dp, dp]),
             "step": (i32, [vp, i32]),
             "rollout": (i32, [vp, i32, i32]),
+            "set_car_policies": (i32, [vp, dp]),
             "get_lidar": (i32, [vp, dp]),
             "get_snapshot": (i32, [vp, dp]),
             "get_pose": (i32, [vp, dp]),
@@ -258,6 +260,14 @@ class Env:
     def rollout(self, policy, n_steps: int):
         p = POLICY_BY_NAME[policy] if isinstance(policy, str) else int(policy)
         self._call("rollout", p, int(n_steps))
+
+    def set_car_policies(self, policies):
+        """The bundled driver of every car slot of an env (names or numbers, one per car of the roster): what
+        ``rollout("per_car", n)`` evaluates.  Replaces the per-vehicle Driver() instances of custom.py:1097-1104."""
+        p = np.array([POLICY_BY_NAME[x] if isinstance(x, str) else int(x) for x in policies], dtype=np.int32)
+        if p.shape != (self.cars_per_env,):
+            raise ValueError(f"one policy per car of an env: expected {self.cars_per_env}, got {p.shape}")
+        self._call("set_car_policies", _ptr(p))
 
     # -- read-backs
     def lidar(self) -> np.ndarray:

@@ -75,6 +75,7 @@ struct FtgpEnv {
     hipEvent_t ev_start = nullptr, ev_stop[2] = { nullptr, nullptr }, ev_metrics = nullptr, ev_gather = nullptr;      // ev_stop: one per metrics slot
     bool timed = false;
     bool ext_launch = true;      // FTGP_LAUNCH_PLAIN=1 switches it off (tools/launch_host.sh)
+    bool last_roster = false;    // the newest launch ran the ROSTER instantiation
     // device buffers
     uint16_t* d_field = nullptr; uint32_t* d_bits = nullptr; uint32_t* d_nearbits = nullptr;
     double* d_path = nullptr; double* d_spawn = nullptr; float* d_ray = nullptr; float* d_cover = nullptr; void* d_veh = nullptr; unsigned char* d_stage = nullptr; DeviceParams* d_params = nullptr;
@@ -212,7 +213,8 @@ int lds_layout(DeviceParams& P, int cpb, int wpb)
     P.off_k1 = o;     o += cpb * (FTGP_FORCE_TERMS * 24 + 4 * 8 + 104);                         // K1 staging: force terms | new wheel spins | new state
     P.mmask_stride = pad16((size_t)2 * (size_t)((P.n_rays + FTGP_WAVE - 1) / FTGP_WAVE + 2));      // two groups per task, never more tasks than groups of 64 rays + 2
     P.off_mmask = o;  if (P.cars_per_env > 1) o += 2 * cpb * P.mmask_stride;              // env-mate visibility masks, double-buffered by step parity
-    P.off_cover = o;  o += pad16(sizeof(float) * (size_t)(P.cover_kmax + 1));             // cover-count thresholds of the launch's driver (last: its size = lds_bytes - off_cover)
+    P.stage_cover = pad16(sizeof(float) * (size_t)(P.cover_kmax + 1));
+    P.off_cover = o;  o += 2 * P.stage_cover;                                               // cover-count thresholds of the launch's driver (FTGP_POLICY_PER_CAR: of both, nidc's first)
     P.lds_bytes = o;
     P.cars_per_block = cpb; P.waves_per_block = wpb;
     return o;
@@ -222,11 +224,21 @@ int lds_layout(DeviceParams& P, int cpb, int wpb)
 // SLOWER per launch -- every query takes the runtime's locks and walks the stream's command list.
 hipError_t wait_event(const FtgpEnv*, hipEvent_t ev) { return hipEventSynchronize(ev); }
 
+// nidc or fast, for every car or for some car of the roster
+bool uses_disparity_driver(const FtgpEnv* e, int policy)
+{
+    if (policy == FTGP_POLICY_NIDC || policy == FTGP_POLICY_FAST) return true;
+    if (policy != FTGP_POLICY_PER_CAR) return false;
+    for (int k = 0; k < e->P.cars_per_env; ++k) if (e->P.car_policy[k] == FTGP_POLICY_NIDC || e->P.car_policy[k] == FTGP_POLICY_FAST) return true;
+    return false;
+}
+
 int launch_steps(FtgpEnv* e, int policy, int n_steps)
 {
     e->rows_valid = false;
     if (n_steps < 0) return fail(FTGP_ERR_ARG, "n_steps < 0%s");
-    if (policy == FTGP_POLICY_NIDC || policy == FTGP_POLICY_FAST) {
+    if (policy == FTGP_POLICY_PER_CAR && !e->P.car_policy[0]) return fail(FTGP_ERR_STATE, "FTGP_POLICY_PER_CAR without ftgp_set_car_policies%s");
+    if (uses_disparity_driver(e, policy)) {
         if (e->P.n_rays < 8) return fail(FTGP_ERR_ARG, "nidc/fast need n_rays >= 8 (they drop len/8 rays from each end)%s");
         if (e->P.n_rays - 2 * e->P.eighth > FTGP_WAVE * FTGP_WAVE) return fail(FTGP_ERR_ARG, "the device drivers handle at most 4096 samples in the front window%s");
     }
@@ -253,10 +265,12 @@ int launch_steps(FtgpEnv* e, int policy, int n_steps)
         const uint32_t lds = (uint32_t)e->P.lds_bytes;
         const bool fake = e->P.lidar_mode == FTGP_LIDAR_FAKELIDAR;
         hipEvent_t ev0 = ext ? e->ev_start : nullptr, ev1 = ext ? e->ev_stop[slot] : nullptr;
-        if (e->multi) { if (fake) hipExtLaunchKernelGGL((ftgp_step_kernel<true, true>), grid, block, lds, e->stream, ev0, ev1, 0, e->d_params, policy, n_steps, slot);
-                        else      hipExtLaunchKernelGGL((ftgp_step_kernel<true, false>), grid, block, lds, e->stream, ev0, ev1, 0, e->d_params, policy, n_steps, slot); }
-        else          { if (fake) hipExtLaunchKernelGGL((ftgp_step_kernel<false, true>), grid, block, lds, e->stream, ev0, ev1, 0, e->d_params, policy, n_steps, slot);
-                        else      hipExtLaunchKernelGGL((ftgp_step_kernel<false, false>), grid, block, lds, e->stream, ev0, ev1, 0, e->d_params, policy, n_steps, slot); }
+        const bool roster = policy == FTGP_POLICY_PER_CAR;
+        e->last_roster = roster;
+#define FTGP_LAUNCH(M, F, R) hipExtLaunchKernelGGL((ftgp_step_kernel<M, F, R>), grid, block, lds, e->stream, ev0, ev1, 0, e->d_params, policy, n_steps, slot)
+        if (e->multi) { if (fake) FTGP_LAUNCH(true, true, true); else if (roster) FTGP_LAUNCH(true, false, true); else FTGP_LAUNCH(true, false, false); }
+        else          { if (fake) FTGP_LAUNCH(false, true, true); else if (roster) FTGP_LAUNCH(false, false, true); else FTGP_LAUNCH(false, false, false); }
+#undef FTGP_LAUNCH
         HIP_TRY(hipGetLastError());
         e->cur_slot = slot;
         e->launch_metrics_valid = e->d_wg_metrics != nullptr;
@@ -512,10 +526,10 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
                 return FTGP_ERR_ARG;
             }
     }
-    CREATE_TRY(hipFuncSetAttribute((const void*)ftgp_step_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    CREATE_TRY(hipFuncSetAttribute((const void*)ftgp_step_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    CREATE_TRY(hipFuncSetAttribute((const void*)ftgp_step_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    CREATE_TRY(hipFuncSetAttribute((const void*)ftgp_step_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#define FTGP_BIG_LDS(M, F, R) CREATE_TRY(hipFuncSetAttribute((const void*)ftgp_step_kernel<M, F, R>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+    FTGP_BIG_LDS(false, false, false); FTGP_BIG_LDS(true, false, false); FTGP_BIG_LDS(false, false, true); FTGP_BIG_LDS(true, false, true);
+    FTGP_BIG_LDS(false, true, true); FTGP_BIG_LDS(true, true, true);
+#undef FTGP_BIG_LDS
 
     // host-side tables
     HostTables tab;
@@ -687,10 +701,10 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
     P.bits = e->d_bits; P.nearbits = e->d_nearbits; P.path = e->d_path; P.spawn = e->d_spawn;
     P.ray_dir = e->d_ray; P.cars = e->d_cars; P.ranges = e->d_ranges; P.steps = e->d_steps;
     {   // the staging image: the LDS bytes [off_params, off_cars) as every workgroup wants them, then both drivers' cover tables
-        const size_t head = (size_t)(P.off_cars - P.off_params), cover = (size_t)(P.lds_bytes - P.off_cover);
+        const size_t head = (size_t)(P.off_cars - P.off_params), cover = (size_t)P.stage_cover;
         std::vector<unsigned char> simg(head + 2 * cover, 0);
         CREATE_TRY(hipMalloc(&e->d_stage, simg.size()));
-        P.stage_img = e->d_stage; P.stage_cover = (int32_t)cover;
+        P.stage_img = e->d_stage;
         memcpy(simg.data() + (P.off_params - P.off_params), &P, offsetof(DeviceParams, veh));
         CREATE_TRY(hipMemcpy(simg.data() + (P.off_veh - P.off_params), e->d_veh, (size_t)pad16(sizeof(VehLds)), hipMemcpyDeviceToHost));
         memcpy(simg.data() + (P.off_path - P.off_params), t.path, sizeof(double) * 2 * FTGP_PATH_POINTS);
@@ -757,8 +771,21 @@ int ftgp_step(FtgpEnv* e, int n_steps)
 int ftgp_rollout(FtgpEnv* e, int policy, int n_steps)
 {
     if (!e) return fail(FTGP_ERR_ARG, "null handle%s");
-    if (policy < FTGP_POLICY_HOST || policy > FTGP_POLICY_RANDOM) return fail(FTGP_ERR_ARG, "unknown policy%s");
+    if (policy < FTGP_POLICY_HOST || policy > FTGP_POLICY_PER_CAR) return fail(FTGP_ERR_ARG, "unknown policy%s");
     return launch_steps(e, policy, n_steps);
+}
+
+int ftgp_set_car_policies(FtgpEnv* e, const int32_t* policies)
+{
+    if (!e || !policies) return fail(FTGP_ERR_ARG, "null argument%s");
+    for (int k = 0; k < e->P.cars_per_env; ++k)
+        if (policies[k] < FTGP_POLICY_LOBOTOMY || policies[k] > FTGP_POLICY_RANDOM) return fail(FTGP_ERR_ARG, "set_car_policies: lobotomy / nidc / fast / random only%s");
+    // a workgroup holds whole envs, so its car slot c runs the roster's entry c % cars_per_env
+    for (int c = 0; c < FTGP_MAX_CARS_PER_BLOCK; ++c) e->P.car_policy[c] = policies[c % e->P.cars_per_env];
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));           // no launch is reading the block while it changes
+    HIP_TRY(hipMemcpy(reinterpret_cast<unsigned char*>(e->d_params) + offsetof(DeviceParams, car_policy), e->P.car_policy, sizeof e->P.car_policy, hipMemcpyHostToDevice));
+    return 0;
 }
 
 int ftgp_get_lidar(FtgpEnv* e, float* out)
@@ -821,8 +848,9 @@ int ftgp_policy_eval(FtgpEnv* e, int policy, const float* ranges, double* ctrl_o
 {
     if (!e || !ranges) return fail(FTGP_ERR_ARG, "null argument%s");
     e->rows_valid = false;
-    if (policy < FTGP_POLICY_LOBOTOMY || policy > FTGP_POLICY_RANDOM) return fail(FTGP_ERR_ARG, "policy_eval: device policies only%s");
-    if (policy == FTGP_POLICY_NIDC || policy == FTGP_POLICY_FAST) {
+    if (policy < FTGP_POLICY_LOBOTOMY || policy > FTGP_POLICY_PER_CAR) return fail(FTGP_ERR_ARG, "policy_eval: device policies only%s");
+    if (policy == FTGP_POLICY_PER_CAR && !e->P.car_policy[0]) return fail(FTGP_ERR_STATE, "FTGP_POLICY_PER_CAR without ftgp_set_car_policies%s");
+    if (uses_disparity_driver(e, policy)) {
         if (e->P.n_rays < 8) return fail(FTGP_ERR_ARG, "nidc/fast need n_rays >= 8%s");
         if (e->P.n_rays - 2 * e->P.eighth > FTGP_WAVE * FTGP_WAVE) return fail(FTGP_ERR_ARG, "the device drivers handle at most 4096 samples in the front window%s");
     }
@@ -1100,8 +1128,10 @@ int ftgp_selftest(int device_id, int64_t* mismatches)
 const char* ftgp_kernel_name(FtgpEnv* e)
 {
     if (!e) return "ftgp_step_kernel";
-    if (e->P.lidar_mode == FTGP_LIDAR_FAKELIDAR) return e->multi ? "ftgp_step_kernel<true, true>" : "ftgp_step_kernel<false, true>";
-    return e->multi ? "ftgp_step_kernel<true, false>" : "ftgp_step_kernel<false, false>";
+    // <MULTI, FAKE, ROSTER>: the instantiation of the newest launch (before any: the single-driver one)
+    if (e->P.lidar_mode == FTGP_LIDAR_FAKELIDAR) return e->multi ? "ftgp_step_kernel<true, true, true>" : "ftgp_step_kernel<false, true, true>";
+    if (e->last_roster) return e->multi ? "ftgp_step_kernel<true, false, true>" : "ftgp_step_kernel<false, false, true>";
+    return e->multi ? "ftgp_step_kernel<true, false, false>" : "ftgp_step_kernel<false, false, false>";
 }
 
 }  // extern "C"

@@ -110,6 +110,8 @@ struct DeviceParams {
     const unsigned char* stage_img;      // what every workgroup stages at the start of a launch, in ONE pass: the image of the LDS bytes [off_params, off_cars)
                                   // (head of this block | VehLds | path | fan), then the cover tables of nidc and of fast, stage_cover bytes each
     int32_t stage_cover, reserved3;
+    int32_t car_policy[FTGP_MAX_CARS_PER_BLOCK];       // FTGP_POLICY_PER_CAR: the driver of the workgroup's car slot c (= the roster's entry c % cars_per_env: a workgroup
+                                  // holds whole envs); 0 = not set.  Read with scalar loads.
     int32_t group_order[FTGP_MAX_GROUPS];      // the tasks of a car by expected march length, longest first (rays along the car's axis look down the
                                   // track, sideways rays hit the corridor wall at once): first ray | kind << 16, kind 0 = one group of 64
                                   // consecutive rays, 1 = that group and the opposite one (first ray + n/2), 2 = the short ends of both halves in

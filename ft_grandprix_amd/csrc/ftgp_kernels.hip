@@ -1577,7 +1577,10 @@ __device__ __forceinline__ void stage16(void* dst, const void* src, int bytes)
 // MULTI: several cars per env (inter-vehicle rays and contacts).  FAKE: FTGP_LIDAR_FAKELIDAR -- the sweep is lidar_fake() (its own
 // instantiation, so that the rangefinder kernels' code generation does not move).  metrics_slot: which of the two record slots this
 // launch's metrics go to (ftgp_metrics_allgather_begin / _end).
-template <bool MULTI, bool FAKE>
+// ROSTER: `policy` may be FTGP_POLICY_PER_CAR (every car slot its own driver, ftgp_set_car_policies) -- again its own instantiation, so
+// that the single-driver kernels stay exactly what they were (the multi-car one lost 3 % to the run-time form of this test); the
+// FAKELIDAR kernels, which are for parity and not for throughput, exist in the ROSTER form only.
+template <bool MULTI, bool FAKE, bool ROSTER>
 __global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(const DeviceParams* __restrict__ Pg, int policy, int n_steps, int metrics_slot)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -1598,7 +1601,9 @@ __global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(cons
     // line, the fan and the driver's cover table: ONE image in HBM laid out as the LDS is (ftgp_create), so that a thread's loads are all in
     // flight together -- the launch pays one memory latency here, not one per table.
     {
-        const int head = Pg->off_cars - Pg->off_params, cover = (policy == FTGP_POLICY_NIDC || policy == FTGP_POLICY_FAST) ? Pg->stage_cover : 0;
+        // (the cover table of the launch's driver; FTGP_POLICY_PER_CAR: both, nidc's first)
+        const int head = Pg->off_cars - Pg->off_params;
+        const int cover = (policy == FTGP_POLICY_NIDC || policy == FTGP_POLICY_FAST) ? Pg->stage_cover : (ROSTER && policy == FTGP_POLICY_PER_CAR) ? 2 * Pg->stage_cover : 0;
         const uint4* img = reinterpret_cast<const uint4*>(Pg->stage_img);
         const uint4* cov = img + ((head + (policy == FTGP_POLICY_FAST ? Pg->stage_cover : 0)) >> 4);
         uint4* d_head = reinterpret_cast<uint4*>(lds + Pg->off_params);
@@ -1620,7 +1625,7 @@ __global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(cons
 #endif
     const int ncars_here = min(cpb, sgpr(P0.n_cars) - ci0);
     const bool second_half = (((int)blockIdx.x / max(1, sgpr(P0.n_cu))) & 1) != 0;      // see sweep_priority(): workgroups b and b + n_cu share a CU in the first dispatch wave
-    const bool need_scan = (policy == FTGP_POLICY_NIDC || policy == FTGP_POLICY_FAST);
+    const bool need_scan = (policy == FTGP_POLICY_NIDC || policy == FTGP_POLICY_FAST || (ROSTER && policy == FTGP_POLICY_PER_CAR));
     {
     const DeviceParams& P = P0;
     const Lds L = lds_view(off, lds);
@@ -1686,7 +1691,13 @@ __global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(cons
 #ifdef FTGP_SWEEP_V1
                 if (!FAKE && need_scan && it > 0) window_flush(G, scan_prev + c * win_floats, ci0 + c);     // the previous sweep's window, before the driver edits it
 #endif
-                if (policy != FTGP_POLICY_HOST) policy_apply(P, driver_shape(G), policy, scan_prev + c * win_floats, L.cars + c, ci0 + c, L.steps[c], L.list + wave * FTGP_WAVE, L.cover);
+                if (ROSTER && policy == FTGP_POLICY_PER_CAR) {
+                    // the roster's drivers: car slot c of the workgroup has its own (wave-uniform: a scalar load); both cover tables are staged
+                    const int pol = G->car_policy[c];
+                    policy_apply(P, driver_shape(G), pol, scan_prev + c * win_floats, L.cars + c, ci0 + c, L.steps[c], L.list + wave * FTGP_WAVE,
+                                 L.cover + (pol == FTGP_POLICY_FAST ? (G->stage_cover >> 2) : 0));
+                }
+                else if (policy != FTGP_POLICY_HOST) policy_apply(P, driver_shape(G), policy, scan_prev + c * win_floats, L.cars + c, ci0 + c, L.steps[c], L.list + wave * FTGP_WAVE, L.cover);
                 wave_lds_sync();
                 // "my controls are in LDS" -> the wave that counts last reads every car's controls: release on this side (the
                 // fence of wave_lds_sync() + the RMW), acquire on the reader's (the RMW + the fence below), workgroup scope
@@ -1756,10 +1767,12 @@ __global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(cons
 #endif
 }
 
-template __global__ void ftgp_step_kernel<false, false>(const DeviceParams*, int, int, int);
-template __global__ void ftgp_step_kernel<true, false>(const DeviceParams*, int, int, int);
-template __global__ void ftgp_step_kernel<false, true>(const DeviceParams*, int, int, int);
-template __global__ void ftgp_step_kernel<true, true>(const DeviceParams*, int, int, int);
+template __global__ void ftgp_step_kernel<false, false, false>(const DeviceParams*, int, int, int);
+template __global__ void ftgp_step_kernel<true, false, false>(const DeviceParams*, int, int, int);
+template __global__ void ftgp_step_kernel<false, false, true>(const DeviceParams*, int, int, int);
+template __global__ void ftgp_step_kernel<true, false, true>(const DeviceParams*, int, int, int);
+template __global__ void ftgp_step_kernel<false, true, true>(const DeviceParams*, int, int, int);
+template __global__ void ftgp_step_kernel<true, true, true>(const DeviceParams*, int, int, int);
 
 // K5 alone: one wave per car evaluates the driver on the scan stored in P.ranges (ftgp_policy_eval).
 __global__ void __launch_bounds__(256) ftgp_policy_kernel(DeviceParams P, int policy, double* __restrict__ ctrl_out)
@@ -1779,7 +1792,8 @@ __global__ void __launch_bounds__(256) ftgp_policy_kernel(DeviceParams P, int po
     if (lane < (int)(sizeof(CarCore) / 4))
         reinterpret_cast<uint32_t*>(st)[lane] = reinterpret_cast<const uint32_t*>(static_cast<const CarCore*>(&P.cars[ci]))[lane];
     wave_lds_sync();
-    policy_apply(P, driver_shape(&P), policy, scan, st, ci, P.steps[ci / P.cars_per_env], list, P.cover_thr + (policy == FTGP_POLICY_FAST ? P.cover_kmax + 1 : 0));
+    const int pol = policy == FTGP_POLICY_PER_CAR ? P.car_policy[ci % P.cars_per_env] : policy;
+    policy_apply(P, driver_shape(&P), pol, scan, st, ci, P.steps[ci / P.cars_per_env], list, P.cover_thr + (pol == FTGP_POLICY_FAST ? P.cover_kmax + 1 : 0));
     wave_lds_sync();
     if (lane == 0) {
         P.cars[ci].u_speed = st->u_speed; P.cars[ci].u_steer = st->u_steer; P.cars[ci].last_steer = st->last_steer;

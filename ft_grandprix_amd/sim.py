@@ -196,9 +196,25 @@ class Simulator:
         for _ in range(n_steps):
             self.step()
 
-    def rollout(self, policy: str, n_steps: int):
-        """n_steps with one of the on-device drivers ("nidc", "fast", "lobotomy", "random") for every car, in ONE launch; the
-        race state -- laps, lap times, finished, winners -- is the same as after n_steps single steps."""
+    # the reference's bundled drivers, restated on the device (K5): roster module path -> device policy
+    BUNDLED = {"ft_grandprix.nidc": "nidc", "ft_grandprix.fast": "fast", "ft_grandprix.lobotomy": "lobotomy"}
+
+    def roster_policies(self) -> Optional[List[str]]:
+        """The device policy of every roster entry, or None when some entry is not one of the reference's bundled drivers
+        (``ft_grandprix.nidc`` / ``.fast`` / ``.lobotomy``, as module path or file:// string, custom.py:1097-1104)."""
+        names = [self.BUNDLED.get(resolve_driver_path(car["driver"]) or "") for car in self.cars]
+        return None if any(n is None for n in names) else names
+
+    def rollout(self, policy: Optional[str], n_steps: int):
+        """n_steps on the device in ONE launch: with one of the on-device drivers ("nidc", "fast", "lobotomy", "random") for every
+        car, or -- policy "roster" / None -- with every car's own bundled driver as the roster names them (template/cars/cars.json:
+        nidc, fast, nidc).  The race state -- laps, lap times, finished, winners -- is the same as after n_steps single steps."""
+        if policy in (None, "roster", "per_car"):
+            names = self.roster_policies()
+            if names is None:
+                raise ValueError("the roster has drivers that exist only in Python: use step() / drive(), or name a device policy")
+            self.env.set_car_policies(names)
+            policy = "per_car"
         self.env.rollout(policy, n_steps)
         self.steps += n_steps
         self._sync_race_state()
@@ -231,8 +247,9 @@ def main(argv=None):
     ap.add_argument("--rays", type=int, default=90, help="rangefinders per car (custom.py:1158 uses 90)")
     ap.add_argument("--envs", type=int, default=1, help="independent copies of the world (every copy runs the whole roster)")
     ap.add_argument("--lap-target", type=int, default=10)
-    ap.add_argument("--device-policy", default=None, choices=("nidc", "fast", "lobotomy", "random"),
-                    help="run the whole loop on the device with this built-in driver for every car (ONE launch) instead of calling the roster's Python drivers")
+    ap.add_argument("--device-policy", default=None, choices=("nidc", "fast", "lobotomy", "random", "roster"),
+                    help="run the whole loop on the device (ONE launch) instead of calling the roster's Python drivers: with this built-in driver "
+                         "for every car, or -- roster -- with each car's own, when the roster names only the reference's bundled drivers")
     ap.add_argument("--lidar", default="rangefinder", choices=("rangefinder", "fakelidar"))
     ap.add_argument("--report", type=int, default=0, help="print the standings every this many steps")
     args = ap.parse_args(argv)

@@ -39,6 +39,7 @@ extern "C" {
 #define FTGP_POLICY_NIDC      2  /* ft_grandprix/nidc.py:116-131 : disparity extender         */
 #define FTGP_POLICY_FAST      3  /* ft_grandprix/fast.py:118-139 : same + straight-line boost */
 #define FTGP_POLICY_RANDOM    4  /* counter-based RNG keyed (seed, car, step): speed~U(0,3), steer~U(-1,1) */
+#define FTGP_POLICY_PER_CAR   5  /* every car slot of an env its own driver, as set by ftgp_set_car_policies (the roster) */
 
 #define FTGP_VEHICLE_MUSHR     0
 #define FTGP_VEHICLE_TRICYCLE  1
@@ -200,6 +201,14 @@ int ftgp_step(FtgpEnv *env, int n_steps);
  * This is the throughput path; one launch covers all n_steps.
  */
 int ftgp_rollout(FtgpEnv *env, int policy, int n_steps);
+
+/*
+ * The roster on the device: policies = int32[cars_per_env], the bundled driver (FTGP_POLICY_LOBOTOMY / NIDC / FAST / RANDOM) of
+ * car slot k of every env; ftgp_rollout(FTGP_POLICY_PER_CAR, n) and ftgp_policy_eval(FTGP_POLICY_PER_CAR, ...) then evaluate each
+ * car with its own driver.  Replaces the per-vehicle Driver() instances the reference builds from the roster's "driver" strings
+ * and calls one by one (custom.py:1097-1104,1398-1411; template/cars/cars.json: nidc, fast, nidc).  Survives ftgp_reset.
+ */
+int ftgp_set_car_policies(FtgpEnv *env, const int32_t *policies);
 
 /* Read-backs (host buffers).  All are synchronous with respect to earlier calls on the handle. */
 

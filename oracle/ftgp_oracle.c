@@ -78,6 +78,7 @@ struct OracleEnv {
     int lidar_mode;          /* 0 = f32 field-accelerated march (== 2 bit for bit), 1 = binary64 plain DDA, 2 = THE SPEC: f32 plain DDA */
     int threads;
     double last_ms;
+    int32_t car_policy[8];   /* FTGP_POLICY_PER_CAR: the driver of car slot k of every env (the roster, custom.py:1097-1104); 0 = not set */
 };
 typedef struct OracleEnv OracleEnv;
 
@@ -807,6 +808,7 @@ static void policy_car(OracleEnv *e, int policy, int ci)
     const int env = ci / e->cfg.cars_per_env;
     const float *r = e->ranges + (size_t)ci * e->cfg.n_rays;
     if (a->finished) { a->u_speed = 0.0; a->u_steer = 0.0; return; }    /* finished cars get the Lobotomy driver, custom.py:1446 */
+    if (policy == FTGP_POLICY_PER_CAR) policy = e->car_policy[ci % e->cfg.cars_per_env];      /* one Driver per vehicle, custom.py:1398-1411 */
     switch (policy) {
     case FTGP_POLICY_LOBOTOMY: a->u_speed = 0.0; a->u_steer = 0.0; break;
     case FTGP_POLICY_NIDC: policy_disparity(e, r, a, 0, &a->u_speed, &a->u_steer); break;
@@ -990,7 +992,8 @@ static int run(OracleEnv *e, int policy, int n_steps)
 int oracle_step(OracleEnv *e, int n_steps) { return run(e, FTGP_POLICY_HOST, n_steps); }
 int oracle_rollout(OracleEnv *e, int policy, int n_steps)
 {
-    if (policy < 0 || policy > FTGP_POLICY_RANDOM) return fail(FTGP_ERR_ARG, "unknown policy");
+    if (policy < 0 || policy > FTGP_POLICY_PER_CAR) return fail(FTGP_ERR_ARG, "unknown policy");
+    if (policy == FTGP_POLICY_PER_CAR && !e->car_policy[0]) return fail(FTGP_ERR_STATE, "FTGP_POLICY_PER_CAR without ftgp_set_car_policies");
     return run(e, policy, n_steps);
 }
 
@@ -1066,12 +1069,21 @@ int oracle_get_ctrl(OracleEnv *e, double *out)
 int oracle_get_steps(OracleEnv *e, int64_t *out) { memcpy(out, e->steps, sizeof(int64_t) * (size_t)e->cfg.n_envs); return 0; }
 int oracle_policy_eval(OracleEnv *e, int policy, const float *ranges, double *ctrl_out)
 {
-    if (policy < FTGP_POLICY_LOBOTOMY || policy > FTGP_POLICY_RANDOM) return fail(FTGP_ERR_ARG, "policy_eval: device policies only");
+    if (policy < FTGP_POLICY_LOBOTOMY || policy > FTGP_POLICY_PER_CAR) return fail(FTGP_ERR_ARG, "policy_eval: device policies only");
+    if (policy == FTGP_POLICY_PER_CAR && !e->car_policy[0]) return fail(FTGP_ERR_STATE, "FTGP_POLICY_PER_CAR without ftgp_set_car_policies");
     memcpy(e->ranges, ranges, sizeof(float) * (size_t)e->n_cars * e->cfg.n_rays);
     for (int i = 0; i < e->n_cars; ++i) {
         policy_car(e, policy, i);
         if (ctrl_out) { ctrl_out[2 * i] = e->cars[i].u_speed; ctrl_out[2 * i + 1] = e->cars[i].u_steer; }
     }
+    return 0;
+}
+int oracle_set_car_policies(OracleEnv *e, const int32_t *policies)
+{
+    if (!e || !policies) return fail(FTGP_ERR_ARG, "null argument");
+    for (int k = 0; k < e->cfg.cars_per_env; ++k)
+        if (policies[k] < FTGP_POLICY_LOBOTOMY || policies[k] > FTGP_POLICY_RANDOM) return fail(FTGP_ERR_ARG, "set_car_policies: lobotomy / nidc / fast / random only");
+    for (int k = 0; k < e->cfg.cars_per_env; ++k) e->car_policy[k] = policies[k];
     return 0;
 }
 int oracle_eval_progress(OracleEnv *e) { for (int i = 0; i < e->n_cars; ++i) progress_car(e, i); return 0; }

@@ -1,0 +1,137 @@
+"""The roster on the device: ftgp_set_car_policies + FTGP_POLICY_PER_CAR -- every car slot of an env its own bundled driver, as the
+reference builds one Driver() per roster entry and calls them one by one (custom.py:1097-1104,1398-1411; template/cars/cars.json is
+nidc, fast, nidc).  Pins: the drivers themselves are pinned by G1 (reference-run controls); here the DISPATCH is checked -- per-car
+launches against single-driver launches, host Python drivers against the device, GPU against oracle."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from ft_grandprix_amd import capi
+from ft_grandprix_amd.track import load_track
+
+ROSTER = ["nidc", "fast", "nidc"]            # template/cars/cars.json:1-5
+
+
+def scans(seed, n_cars, n_rays):
+    rng = np.random.default_rng(seed)
+    r = rng.uniform(0.2, 8.0, size=(n_cars, n_rays)).astype(np.float32)
+    r[:, ::7] *= 0.3                          # disparities
+    return r
+
+
+def check_dispatch(lib, n_rays=90):
+    """policy_eval("per_car") = every car evaluated by its own driver's single-policy call."""
+    t = load_track("track")
+    with capi.Env(lib, t, n_envs=5, cars_per_env=3, n_rays=n_rays) as e:
+        r = scans(3, e.n_cars, n_rays)
+        e.set_car_policies(ROSTER)
+        mixed = e.policy_eval("per_car", r)
+        single = {p: e.policy_eval(p, r) for p in set(ROSTER)}
+        for ci in range(e.n_cars):
+            np.testing.assert_array_equal(mixed[ci], single[ROSTER[ci % 3]][ci])
+        assert not np.array_equal(single["nidc"], single["fast"])          # the two drivers do differ on these scans
+
+
+def test_oracle_per_car_dispatch(oracle):
+    check_dispatch(oracle)
+
+
+def test_per_car_needs_a_roster_and_bundled_drivers(oracle):
+    t = load_track("small-circle")
+    with capi.Env(oracle, t, n_envs=2, cars_per_env=2, n_rays=36) as e:
+        with pytest.raises(capi.FtgpError) as ei:
+            e.rollout("per_car", 1)
+        assert ei.value.code == -4
+        with pytest.raises(capi.FtgpError):
+            e.set_car_policies(["nidc", "host"])
+        with pytest.raises(ValueError):
+            e.set_car_policies(["nidc"])
+        e.set_car_policies(["lobotomy", "random"])
+        e.rollout("per_car", 3)
+        ctrl = e.ctrl()
+        assert (ctrl[0::2] == 0).all() and (ctrl[1::2, 0] > 0).all()
+
+
+REF = "/root/reference"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present")
+def test_reference_roster_with_its_own_drivers_against_one_device_rollout(oracle):
+    """template/cars/cars.json -- nidc, fast, nidc -- driven by the reference's OWN driver objects, one per car, step by step
+    (sim.Simulator, the host path) against ONE rollout("roster"): the closed loops stay together (the Python drivers see binary64
+    copies of the binary32 scans; the restated K5 agrees to rounding, as in test_unmodified_reference_drivers_close_the_loop)."""
+    from ft_grandprix_amd.sim import Simulator
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    roster = Simulator.load_roster(os.path.join(REF, "template", "cars", "cars.json"))
+    t = load_track("track")
+    host = Simulator(t, roster, n_envs=2, n_rays=90, lib=oracle)
+    dev = Simulator(t, roster, n_envs=2, n_rays=90, lib=oracle)
+    try:
+        assert host.roster_policies() == ROSTER
+        assert [type(vs.driver).__module__ for vs in host.vehicle_states[:3]] == ["ft_grandprix.nidc", "ft_grandprix.fast", "ft_grandprix.nidc"]
+        with np.errstate(all="ignore"):
+            host.drive(250)
+        dev.rollout("roster", 250)
+        np.testing.assert_array_equal(host.env.progress(), dev.env.progress())
+        np.testing.assert_allclose(host.env.pose(), dev.env.pose(), rtol=0, atol=1e-6)
+        np.testing.assert_allclose(host.env.ctrl(), dev.env.ctrl(), rtol=0, atol=1e-6)
+        assert [vs.laps for vs in host.vehicle_states] == [vs.laps for vs in dev.vehicle_states]
+    finally:
+        host.close(); dev.close()
+
+
+def test_roster_of_python_only_drivers_is_not_taken_to_the_device(oracle):
+    from ft_grandprix_amd.sim import Simulator
+    sim = Simulator(load_track("small-circle"), [{"driver": "ft_grandprix_amd.drivers.follow_gap", "name": "own"}], n_rays=36, lib=oracle)
+    try:
+        assert sim.roster_policies() is None
+        with pytest.raises(ValueError):
+            sim.rollout("roster", 5)
+        sim.rollout("lobotomy", 5)
+    finally:
+        sim.close()
+
+
+@pytest.mark.gpu
+def test_gpu_per_car_dispatch(product):
+    check_dispatch(product)
+    check_dispatch(product, n_rays=1080)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,roster,rays", [("track", ROSTER, 1080), ("circle", ["fast", "random", "lobotomy", "nidc"], 90),
+                                              ("inkscape", ["fast"], 360)])
+def test_gpu_roster_rollout_matches_the_oracle(product, oracle, name, roster, rays):
+    """Closed loop with the roster's drivers on the device, GPU against oracle: scans, controls, race state bit for bit; in one
+    launch and step by step."""
+    t = load_track(name)
+    kw = dict(n_envs=24, cars_per_env=len(roster), n_rays=rays, spawn_mode=1, seed=5)
+    with capi.Env(product, t, **kw) as g, capi.Env(oracle, t, **kw) as o:
+        oracle.dll.oracle_set_threads(o.h, 8)
+        g.set_car_policies(roster); o.set_car_policies(roster)
+        for n in (1, 1, 60, 240):
+            g.rollout("per_car", n); o.rollout("per_car", n)
+            np.testing.assert_array_equal(g.lidar(), o.lidar())
+            np.testing.assert_array_equal(g.ctrl(), o.ctrl())
+            np.testing.assert_array_equal(g.progress(), o.progress())
+            np.testing.assert_allclose(g.pose(), o.pose(), rtol=0, atol=1e-12)
+        g.reset(); o.reset()                               # the roster survives a reset
+        g.rollout("per_car", 30); o.rollout("per_car", 30)
+        np.testing.assert_array_equal(g.lidar(), o.lidar())
+
+
+@pytest.mark.gpu
+def test_gpu_single_driver_roster_equals_the_single_policy_launch(product):
+    """A roster of one driver is the single-policy launch: same kernel, same bits (and the cover table of the right driver)."""
+    t = load_track("track")
+    kw = dict(n_envs=16, n_rays=1080, spawn_mode=1, seed=9)
+    for p in ("fast", "nidc"):
+        with capi.Env(product, t, **kw) as a, capi.Env(product, t, **kw) as b:
+            b.set_car_policies([p])
+            a.rollout(p, 200); b.rollout("per_car", 200)
+            np.testing.assert_array_equal(a.lidar(), b.lidar())
+            np.testing.assert_array_equal(a.pose(), b.pose())
+            np.testing.assert_array_equal(a.ctrl(), b.ctrl())

@@ -79,8 +79,8 @@ def code_object_meta(lib=None):
         name = re.search(r"\.name:\s+(\S+)", block)
         if not name or "ftgp_step_kernel" not in name.group(1):
             continue
-        flags = re.search(r"ftgp_step_kernelILb(\d)ELb(\d)E", name.group(1))
-        key = "ftgp_step_kernel<%s, %s>" % tuple("true" if f == "1" else "false" for f in flags.groups()) if flags else name.group(1)
+        flags = re.search(r"ftgp_step_kernelILb(\d)ELb(\d)ELb(\d)E", name.group(1))
+        key = "ftgp_step_kernel<%s, %s, %s>" % tuple("true" if f == "1" else "false" for f in flags.groups()) if flags else name.group(1)
         get = lambda k: int(re.search(r"\.%s:\s+(\d+)" % k, block).group(1))
         out[key] = {"vgpr_count": get("vgpr_count"), "sgpr_count": get("sgpr_count"), "sgpr_spill_count": get("sgpr_spill_count"),
                     "vgpr_spill_count": get("vgpr_spill_count"), "scratch_bytes_per_lane": get("private_segment_fixed_size"),
