@@ -135,3 +135,25 @@ def test_gpu_single_driver_roster_equals_the_single_policy_launch(product):
             np.testing.assert_array_equal(a.lidar(), b.lidar())
             np.testing.assert_array_equal(a.pose(), b.pose())
             np.testing.assert_array_equal(a.ctrl(), b.ctrl())
+
+
+@pytest.mark.gpu
+def test_gpu_runner_takes_the_reference_roster_to_the_device(product, tmp_path, capsys):
+    """python -m ft_grandprix_amd.sim --cars <cars.json layout> --device-policy roster: the file's driver strings (module path and
+    file:// form, custom.py:1097-1104) pick the device drivers; the race state equals a direct per-car rollout."""
+    import json
+    from ft_grandprix_amd import sim as simmod
+    roster = [{"driver": "ft_grandprix.nidc", "name": "red car"}, {"driver": "file://ft_grandprix/fast.py", "name": "orange car"},
+              {"driver": "ft_grandprix.nidc", "name": "green car"}]
+    f = tmp_path / "cars.json"
+    f.write_text(json.dumps(roster))
+    assert simmod.main(["--cars", str(f), "--track", "track", "--steps", "600", "--envs", "2", "--rays", "90", "--device-policy", "roster"]) == 0
+    out = capsys.readouterr().out
+    assert "after 600 steps" in out and "red car" in out and "orange car" in out
+    with capi.Env(product, load_track("track"), n_envs=2, cars_per_env=3, n_rays=90) as e:
+        e.set_car_policies(ROSTER)
+        e.rollout("per_car", 600)
+        prog = e.progress()
+    for label, row in zip(("red car", "orange car", "green car"), prog[:3]):
+        line = next(x for x in out.splitlines() if label in x)
+        assert f"laps {int(row[0]):3d}" in line
