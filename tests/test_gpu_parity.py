@@ -472,6 +472,26 @@ def test_results_do_not_depend_on_the_sector_count(product, oracle, sectors):
         del os.environ["FTGP_SECTORS_RT"]
 
 
+def test_launch_with_recorded_events_gives_the_same_results(product):
+    """FTGP_LAUNCH_PLAIN=1 (hipEventRecord around the launch instead of events on the dispatch packet): same results, and a kernel
+    time of the same order."""
+    import os
+    t = load_track("track")
+    kw = dict(n_envs=64, n_rays=1080, spawn_mode=1, seed=4)
+    with capi.Env(product, t, **kw) as a:
+        a.rollout("fast", 150); ms_a = a.last_kernel_ms()
+        os.environ["FTGP_LAUNCH_PLAIN"] = "1"
+        try:
+            with capi.Env(product, t, **kw) as b:
+                b.rollout("fast", 150); ms_b = b.last_kernel_ms()
+                np.testing.assert_array_equal(a.lidar(), b.lidar())
+                np.testing.assert_array_equal(a.pose(), b.pose())
+                np.testing.assert_array_equal(a.metrics_local(), b.metrics_local())
+        finally:
+            del os.environ["FTGP_LAUNCH_PLAIN"]
+    assert 0.0 < ms_a < 10 * ms_b and ms_b < 10 * ms_a
+
+
 def test_gpu_shards_reproduce_the_monolithic_batch(product):
     """a shard [env_base, env_base + n) must equal the same slice of the whole batch (two handles, one GPU)."""
     from ft_grandprix_amd import dist as ftdist

@@ -16,7 +16,8 @@ lib, ora = capi.load(), load_oracle()
 bad = 0
 for name in ("track", "circle", "small-circle", "inkscape"):
     t = load_track(name)
-    for policy, cars, rays in (("fast", 1, 1080), ("nidc", 1, 1080), ("random", 1, 1080), ("fast", 4, 360)):
+    # ("roster", 3, ...): template/cars/cars.json -- nidc, fast, nidc -- with every car's own driver on the device (FTGP_POLICY_PER_CAR)
+    for policy, cars, rays in (("fast", 1, 1080), ("nidc", 1, 1080), ("random", 1, 1080), ("fast", 4, 360), ("roster", 3, 1080)):
         n_big = 4096 if cars == 1 else 1024
         kw = dict(cars_per_env=cars, n_rays=rays, spawn_mode=1 if cars == 1 else 0, seed=99)
         t0 = time.time()
@@ -26,10 +27,14 @@ for name in ("track", "circle", "small-circle", "inkscape"):
         with capi.Env(lib, t, n_envs=n_big, **kw) as g, capi.Env(ora, t, n_envs=envs, **kw) as o, capi.Env(lib, t, n_envs=n_big, **kw) as twin:
             ora.dll.oracle_set_threads(o.h, 16)
             n = envs * cars
+            if policy == "roster":
+                for e in (g, o, twin):
+                    e.set_car_policies(["nidc", "fast", "nidc"])
             for done in range(0, steps, chunk):
-                g.rollout(policy, chunk); o.rollout(policy, chunk)
+                p = "per_car" if policy == "roster" else policy
+                g.rollout(p, chunk); o.rollout(p, chunk)
                 for part in (chunk // 5, chunk - chunk // 5):
-                    twin.rollout(policy, part)
+                    twin.rollout(p, part)
                 same = (np.array_equal(g.lidar()[:n], o.lidar()) and np.array_equal(g.progress()[:n], o.progress())
                         and np.array_equal(g.pose()[:n], o.pose()) and np.array_equal(g.ctrl()[:n], o.ctrl())
                         and np.array_equal(g.lidar(), twin.lidar()) and np.array_equal(g.pose(), twin.pose()) and np.array_equal(g.progress(), twin.progress()))
