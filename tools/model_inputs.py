@@ -21,7 +21,10 @@ with capi.Env(ora, t, n_envs=envs, cars_per_env=cars, n_rays=1080, spawn_mode=1 
     ora.dll.oracle_set_threads(o.h, 8)
     o.rollout(policy, steps)
     p = o.pose()
-with open("/tmp/poses.bin", "wb") as f:
-    f.write(struct.pack("<6d", len(p), t.px_size_x, t.px_size_y, t.origin_x, t.origin_y, 0.0))
-    f.write(np.ascontiguousarray(p[:, [0, 1, 3, 6]]).tobytes())
-print("wrote /tmp/track.raw /tmp/poses.bin:", len(p), "cars after", steps, "steps of", policy)
+    o.rollout(policy, 1)
+    p_next = o.pose()            # the same cars one step later (what-ifs that carry something from step to step: PREV=/tmp/poses_next.bin)
+for path, q in (("/tmp/poses.bin", p), ("/tmp/poses_next.bin", p_next)):
+    with open(path, "wb") as f:
+        f.write(struct.pack("<6d", len(q), t.px_size_x, t.px_size_y, t.origin_x, t.origin_y, 0.0))
+        f.write(np.ascontiguousarray(q[:, [0, 1, 3, 6]]).tobytes())
+print("wrote /tmp/track.raw /tmp/poses.bin /tmp/poses_next.bin:", len(p), "cars after", steps, "steps of", policy)

@@ -122,10 +122,16 @@ int main(int argc, char** argv)
     }
     const int iso_mode = getenv("ISO") ? atoi(getenv("ISO")) : 0;
     long iso_used = 0, iso_near = 0;
+    std::vector<double> pose_next;
+    if (getenv("NEXT")) {          // the same cars one step later (tools/model_inputs.py): what-ifs that sort by the PREVIOUS step's counts
+        FILE* fn = fopen(getenv("NEXT"), "rb"); double phn[6];
+        if (fn && fread(phn, 8, 6, fn) == 6 && (int)phn[0] == n_cars) { pose_next.resize((size_t)n_cars * 4); if (fread(pose_next.data(), 8, pose_next.size(), fn) != pose_next.size()) pose_next.clear(); }
+        if (fn) fclose(fn);
+    }
     if (getenv("HIST")) {          // iterations per ray, and per group of 64 consecutive rays (= the slowest ray of the group): lidar_groups
         std::vector<long> hr(64, 0), hg(64, 0); long sum_g = 0, ng = 0, sum_r = 0;
         std::vector<long> by_index(R, 0);
-        long alt_sum[4] = { 0, 0, 0, 0 };
+        long alt_sum[4] = { 0, 0, 0, 0 }, nx_sum[5] = { 0, 0, 0, 0, 0 };
         for (int c = 0; c < n_cars; ++c) {
             const double* p = &pose[(size_t)c * 4];
             const double ch = 1.0 - 2.0 * (p[3] * p[3]), sh = 2.0 * (p[2] * p[3]);
@@ -163,9 +169,55 @@ int main(int argc, char** argv)
             alt_sum[1] += grouped([&](int j) { return (double)range_of[j]; });
             alt_sum[2] += grouped([&](int j) { return floor((double)range_of[j] * 4.0); });
             alt_sum[3] += grouped([&](int j) { return floor((double)range_of[j] * 1.0); });
+            if (!pose_next.empty()) {          // counts of THIS pose as the key, counts one step later as the cost
+                std::vector<int> cnt_next(R);
+                const double* q = &pose_next[(size_t)c * 4];
+                const double ch2 = 1.0 - 2.0 * (q[3] * q[3]), sh2 = 2.0 * (q[2] * q[3]);
+                const double lx2 = q[0] + (ch2 * -0.0525), ly2 = q[1] + (sh2 * -0.0525);
+                const float u2 = (float)((lx2 - ph[3]) * (1.0 / ph[1])), v2 = (float)((ph[4] - ly2) * (1.0 / ph[2]));
+                const float c2 = (float)ch2, s2 = (float)sh2;
+                for (int j = 0; j < R; ++j) {
+                    const float dxw = fmaf(c2, bx[j], -(s2 * by[j])), dyw = fmaf(s2, bx[j], c2 * by[j]);
+                    const float du = dxw * isx, dv = -(dyw * isy);
+                    FtgpRay r; ftgp_ray_init(r, fmaf(du, -r0, u2), fmaf(dv, -r0, v2), du, dv, fabsf(1.0f / du), fabsf(1.0f / dv), W, H, fstride, plane256);
+                    int n = 1;
+                    for (; n < 100000; ++n) {
+                        const uint32_t wq = field[ftgp_ray_offset(r) >> 1];
+                        FtgpStep st; const bool near = ftgp_ray_step(r, wq, eps, st);
+                        ftgp_ray_commit(r, st, near ? ftgp_ray_fix(r, st) : st.t);
+                        if (!st.live) break;
+                    }
+                    cnt_next[j] = n;
+                }
+                auto cost_next = [&](const std::vector<int>& idx, int n_idx) {
+                    long sum = 0; int m = 0;
+                    for (int k = 0; k < n_idx; ++k) { m = std::max(m, cnt_next[idx[k]]); if ((k & 63) == 63 || k == n_idx - 1) { sum += m; m = 0; } }
+                    return sum;
+                };
+                std::vector<int> idx(R); for (int j = 0; j < R; ++j) idx[j] = j;
+                nx_sum[0] += cost_next(idx, R);                                                     // neighbours, next step (the baseline there)
+                std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return cnt_of[a] > cnt_of[b]; });
+                nx_sum[1] += cost_next(idx, R);                                                     // sorted by the previous step's count
+                std::vector<int> cl(R); for (int j = 0; j < R; ++j) cl[j] = std::min(cnt_of[j], 6);  // ... by its count clipped to 6 (3 bits per ray)
+                for (int j = 0; j < R; ++j) idx[j] = j;
+                std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return cl[a] > cl[b]; });
+                nx_sum[2] += cost_next(idx, R);
+                // pairs kept: first-half rays sorted by max(count[j], count[j + R/2]); a group and its opposite are marched one after the other
+                const int half = R / 2;
+                std::vector<int> hi(half); for (int j = 0; j < half; ++j) hi[j] = j;
+                std::stable_sort(hi.begin(), hi.end(), [&](int a, int b) { return std::max(cnt_of[a], cnt_of[a + half]) > std::max(cnt_of[b], cnt_of[b + half]); });
+                std::vector<int> opp(half); for (int k = 0; k < half; ++k) opp[k] = hi[k] + half;
+                nx_sum[3] += cost_next(hi, half) + cost_next(opp, half);
+                for (int j = 0; j < half; ++j) hi[j] = j;
+                for (int k = 0; k < half; ++k) opp[k] = k + half;
+                nx_sum[4] += cost_next(hi, half) + cost_next(opp, half);                            // neighbours in pairs (what ships, ignoring the mixed group)
+            }
         }
         printf("what-if, wave-iterations per car-step with groups of 64 after sorting a car's rays: by true count %.1f, by range %.1f, by range in 1/4-unit bins %.1f, in 1-unit bins %.1f\n",
                (double)alt_sum[0] / n_cars, (double)alt_sum[1] / n_cars, (double)alt_sum[2] / n_cars, (double)alt_sum[3] / n_cars);
+        if (!pose_next.empty())
+            printf("one step later: neighbours %.1f; sorted by the previous step's count %.1f, by that count clipped to 6: %.1f; pairs kept, sorted by the pair's larger count %.1f (neighbours in pairs %.1f)\n",
+                   (double)nx_sum[0] / n_cars, (double)nx_sum[1] / n_cars, (double)nx_sum[2] / n_cars, (double)nx_sum[3] / n_cars, (double)nx_sum[4] / n_cars);
         printf("iterations per ray: mean %.2f; per group of 64: mean %.2f (x %.1f groups per car = %.1f wave-iterations per car-step)\n", (double)sum_r / ((double)n_cars * R), (double)sum_g / ng, (double)ng / n_cars, (double)sum_g / n_cars);
         printf("  n    rays%%  groups%%\n");
         for (int n = 1; n < 64; ++n) if (hr[n] || hg[n]) printf("%3d  %6.2f  %6.2f\n", n, 100.0 * hr[n] / ((double)n_cars * R), 100.0 * hg[n] / ng);
