@@ -463,23 +463,27 @@ __device__ __forceinline__ void lidar_pool(const DeviceParams& P, ScalarParams G
 // In: exec = the lanes that hold a ray; ix, iy = (mirrored) cell, s = crossing time into it (0 at the origin).
 // Out: w = entry of the terminal cell (0 = wall, FTGP_FIELD_OUT = ring), s = crossing time into it, exec as on entry.
 // The arithmetic is ftgp_ray_step / ftgp_ray_fix / ftgp_ray_commit of ftgp_march.h, instruction for instruction.
+// off0: the byte offset of the start cell's entry (ftgp_ray_offset_first: the first look-up may be served by a plane of its own, a finer
+// sector than the rest of the march uses).
 __device__ __forceinline__ void march_all(int& ix, int& iy, float& s, uint32_t& w, float pum, float pvm, float ivx, float ivy, float dum, float dvm,
-                                          int offC, int ax, int ay, float thr /* 0.5f - eps */, const void* field)
+                                          int off0, int offC, int ax, int ay, float thr /* 0.5f - eps */, const void* field)
 {
-    int a, b, c, d, e, f, h, i;
+    int a = off0, b, c, d, e, f, h, i;
     uint64_t stepx, sv, sq, ex0;
     asm volatile(
         "s_mov_b64 %[ex0], exec\n\t"
         // the look-up of the cell a ray stands on: entry offset = ftgp_ray_offset(), far corner of its box, "is it a box at all"
-#define FTGP_MARCH_LOOKUP \
-        "v_mad_i32_i24 %[a], %[iy], %[ay], %[offC]\n\t" \
-        "v_mad_i32_i24 %[a], %[ix], %[ax], %[a]\n\t" \
+#define FTGP_MARCH_LOAD \
         "global_load_ushort %[w], %[a], %[field]\n\t" \
         "s_waitcnt vmcnt(0)\n\t" \
         "v_add_u32_sdwa %[c], %[ix], %[w] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"     /* xe = ix + kx */ \
         "v_add_u32_sdwa %[d], %[iy], %[w] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t"     /* ye = iy + ky */ \
         "v_cmpx_ne_u32_e32 vcc, %[c], %[ix]\n\t"                         /* kx == 0: wall or ring cell -- the lane is done */
-        FTGP_MARCH_LOOKUP
+#define FTGP_MARCH_LOOKUP \
+        "v_mad_i32_i24 %[a], %[iy], %[ay], %[offC]\n\t" \
+        "v_mad_i32_i24 %[a], %[ix], %[ax], %[a]\n\t" \
+        FTGP_MARCH_LOAD
+        FTGP_MARCH_LOAD                                                   // the start cell: its offset comes in with `a`
         "s_cbranch_execz L_march_done_%=\n"
         "L_march_loop_%=:\n\t"
         "v_cvt_f32_i32_e32 %[a], %[c]\n\t"
@@ -527,7 +531,7 @@ __device__ __forceinline__ void march_all(int& ix, int& iy, float& s, uint32_t& 
         "L_march_done_%=:\n\t"
         "s_mov_b64 exec, %[ex0]"
         : [ix] "+v"(ix), [iy] "+v"(iy), [s] "+v"(s), [w] "+v"(w),
-          [a] "=&v"(a), [b] "=&v"(b), [c] "=&v"(c), [d] "=&v"(d), [e] "=&v"(e), [f] "=&v"(f), [h] "=&v"(h), [i] "=&v"(i),
+          [a] "+v"(a), [b] "=&v"(b), [c] "=&v"(c), [d] "=&v"(d), [e] "=&v"(e), [f] "=&v"(f), [h] "=&v"(h), [i] "=&v"(i),
           [stepx] "=&s"(stepx), [sv] "=&s"(sv), [sq] "=&s"(sq), [ex0] "=&s"(ex0)
         : [pum] "v"(pum), [pvm] "v"(pvm), [ivx] "v"(ivx), [ivy] "v"(ivy), [dum] "v"(dum), [dvm] "v"(dvm),
           [offC] "v"(offC), [ax] "v"(ax), [ay] "v"(ay), [thr] "s"(thr), [field] "s"(field)
@@ -587,7 +591,7 @@ __device__ __forceinline__ void lidar_groups(const DeviceParams& P, ScalarParams
             if (!active) return;
             uint32_t w = FTGP_FIELD_OUT;
             STAMP(tb);
-            march_all(ray.ix, ray.iy, ray.s, w, ray.pum, ray.pvm, ray.ivx, ray.ivy, ray.dum, ray.dvm, ray.offC, ray.ax, ray.ay, thr, field);
+            march_all(ray.ix, ray.iy, ray.s, w, ray.pum, ray.pvm, ray.ivx, ray.ivy, ray.dum, ray.dvm, ftgp_ray_offset_first(ray), ray.offC, ray.ax, ray.ay, thr, field);
             STAMP(tc); STAMP_ADD(10, tc - tb); STAMP_ADD(9, 1);
             float r = (w == 0u) ? fabsf(ray.s) : ray.result;
 #ifdef FTGP_ABLATE_MATES      // diagnostic (timing only, wrong results): what the inter-vehicle tests cost

@@ -114,7 +114,9 @@ struct FtgpRay {
     float pum, pvm, dum, dvm, ivx, ivy;   // mirrored origin, |direction|, |1 / direction| (+inf where the direction is 0)
     float s, result;                      // crossing time of the last step; range when the ray ends on no wall (-1, see ftgp_ray_range)
     int ix, iy;                           // mirrored cell
-    int offC, ax, ay;
+    int offC, ax, ay;                     // byte offset of cell (ix, iy) in the field = iy * ay + ix * ax + offC
+    int offF;                             // the same constant for the ray's FIRST look-up (its start cell), which may use a plane of its own: a
+                                          // finer direction sector costs nothing in cache there -- all rays of a car start in one cell
 };
 
 // A ray that marches nothing: every cell of it maps to ring cell (0, 0) of plane 0, which terminates at once and leaves `result` alone.
@@ -122,7 +124,7 @@ FTGP_HD void ftgp_ray_park(FtgpRay& r, float result)
 {
     r.pum = r.pvm = r.dum = r.dvm = r.ivx = r.ivy = 0.0f;
     r.s = 0.0f; r.result = result;
-    r.ix = r.iy = 0; r.offC = 0; r.ax = r.ay = 0;
+    r.ix = r.iy = 0; r.offC = r.offF = 0; r.ax = r.ay = 0;
 }
 
 // fstride = W + 2 (cells per plane row); plane256 = bytes per sector plane / 256 (planes are padded to a multiple of 256 B);
@@ -130,14 +132,32 @@ FTGP_HD void ftgp_ray_park(FtgpRay& r, float result)
 // assume_inside (a compile-time constant at every call site): the caller guarantees that (pu, pv) is finite and lies on the
 // image -- the step kernel does when every LiDAR centre of the workgroup is a ring radius plus two pixels away from the image
 // edge (frame_write) -- so the test, and the selects that park an off-image ray, are not needed.
-// sector_tab (optional, [FTGP_SECTORS][4] as ftgp_sector_entry() fills it): offC, ax, ay of every sector precomputed, one 16-byte
+// sector_tab (optional, [FTGP_SECTORS][4] as ftgp_sector_entry() fills it): offF, ax, ay, offC of every sector precomputed, one 16-byte
 // read instead of eight integer instructions.
-FTGP_HD void ftgp_sector_entry(int32_t* e, uint32_t sector, int fstride, uint32_t plane256)
+// plane_first / plane_rest: which plane of the field serves a ray of this sector at its first look-up / afterwards (one field: both = sector)
+FTGP_HD void ftgp_sector_entry(int32_t* e, uint32_t sector, int fstride, uint32_t plane256, uint32_t plane_first, uint32_t plane_rest)
 {
     const int mxm = -(int)(sector & 1u), mym = -(int)((sector >> 1) & 1u);
     const int hy = (fstride ^ mym) - mym;
-    e[0] = (int)((sector * plane256) << 8) + (fstride + 2) + (mxm + mxm) + hy;
-    e[1] = 2 + 4 * mxm; e[2] = hy + hy; e[3] = 0;
+    const int mirror = (fstride + 2) + (mxm + mxm) + hy;
+    e[0] = (int)((plane_first * plane256) << 8) + mirror;
+    e[1] = 2 + 4 * mxm; e[2] = hy + hy;
+    e[3] = (int)((plane_rest * plane256) << 8) + mirror;
+}
+FTGP_HD void ftgp_sector_entry(int32_t* e, uint32_t sector, int fstride, uint32_t plane256) { ftgp_sector_entry(e, sector, fstride, plane256, sector, sector); }
+
+// The sector table of a field that holds `coarse` sectors' planes for every look-up but the first, and -- fine_first -- all FTGP_SECTORS
+// planes in front of them for the first one.  A ray's sector is always found among FTGP_SECTORS; the coarse sector it belongs to has the
+// same mirror / axis bits and its slope slice shifted down (the coarse slices are unions of fine ones).  Returns the number of planes.
+FTGP_HD int ftgp_sector_table(int32_t (*tab)[4], int coarse, bool fine_first, int fstride, uint32_t plane256)
+{
+    int shift = 0; while ((FTGP_SECTORS >> shift) > coarse) ++shift;
+    const bool two = fine_first && coarse != FTGP_SECTORS;
+    for (uint32_t s = 0; s < (uint32_t)FTGP_SECTORS; ++s) {
+        const uint32_t sc = ((s >> 3) >> shift) << 3 | (s & 7u);
+        ftgp_sector_entry(tab[s], s, fstride, plane256, two ? s : sc, two ? (uint32_t)FTGP_SECTORS + sc : sc);
+    }
+    return two ? FTGP_SECTORS + coarse : coarse;
 }
 
 // Sector of a direction: (mirror x) | (mirror y) << 1 | (y-dominant) << 2 | (slope slice) << 3.  Mirrors and dominant axis come out of
@@ -198,12 +218,12 @@ FTGP_HD void ftgp_ray_place(FtgpRay& r, float pu, float pv, float du, float dv, 
     if (sector_tab) {
 #if defined(__HIP_DEVICE_COMPILE__)
         const int4 e4 = reinterpret_cast<const int4*>(sector_tab)[sector];       // one 16-byte LDS read
-        r.offC = e4.x; r.ax = e4.y; r.ay = e4.z;
+        r.offF = e4.x; r.ax = e4.y; r.ay = e4.z; r.offC = e4.w;
 #else
         const int32_t* e = sector_tab + 4 * sector;
-        r.offC = e[0]; r.ax = e[1]; r.ay = e[2];
+        r.offF = e[0]; r.ax = e[1]; r.ay = e[2]; r.offC = e[3];
 #endif
-        if (!inside) { r.offC = 0; r.ax = r.ay = 0; }
+        if (!inside) { r.offC = r.offF = 0; r.ax = r.ay = 0; }
         return;
     }
     const int hy = (fstride ^ mym) - mym;                     // +-fstride
@@ -215,8 +235,8 @@ FTGP_HD void ftgp_ray_place(FtgpRay& r, float pu, float pv, float du, float dv, 
 #else
     const uint32_t plane = sector * plane256;
 #endif
-    r.offC = (int)(plane << 8) + (fstride + 2) + (mxm + mxm) + hy;
-    if (!inside) { r.offC = 0; r.ax = r.ay = 0; }             // starts off the image: every cell maps to ring cell (0, 0) of plane 0, result stays -1
+    r.offC = r.offF = (int)(plane << 8) + (fstride + 2) + (mxm + mxm) + hy;
+    if (!inside) { r.offC = r.offF = 0; r.ax = r.ay = 0; }    // starts off the image: every cell maps to ring cell (0, 0) of plane 0, result stays -1
 }
 
 FTGP_HD void ftgp_ray_init(FtgpRay& r, float pu, float pv, float du, float dv, float ivx, float ivy, int W, int H, int fstride, uint32_t plane256,
@@ -238,7 +258,20 @@ FTGP_HD void ftgp_ray_park_if_outside(FtgpRay& r, float pu, float pv, int W, int
     const float fx = floorf(pu), fy = floorf(pv);
     const bool inside = fx >= 0.0f && fx < (float)W && fy >= 0.0f && fy < (float)H;
 #endif
-    if (!inside) { r.offC = 0; r.ax = r.ay = 0; }
+    if (!inside) { r.offC = r.offF = 0; r.ax = r.ay = 0; }
+}
+
+// byte offset of the ray's start cell in the plane of its first look-up
+FTGP_HD int ftgp_ray_offset_first(const FtgpRay& r)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    int a, b;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(a) : "v"(r.iy), "v"(r.ay), "v"(r.offF));
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(b) : "v"(r.ix), "v"(r.ax), "v"(a));
+    return b;
+#else
+    return r.ix * r.ax + (r.iy * r.ay + r.offF);
+#endif
 }
 
 FTGP_HD int ftgp_ray_offset(const FtgpRay& r)
@@ -328,14 +361,15 @@ FTGP_HD void ftgp_ray_commit(FtgpRay& r, const FtgpStep& st, int t, bool hold = 
 FTGP_HD float ftgp_ray_range(const FtgpRay& r, uint32_t w) { return w == 0u ? fabsf(r.s) : r.result; }
 
 // single ray against a field image (host harness, tests)
-FTGP_HD float ftgp_march_one(const uint16_t* field, int W, int H, float eps, float pu, float pv, float du, float dv)
+// (sector_tab: as ftgp_create builds it -- the first look-up may use a plane of a finer sector count than the rest)
+FTGP_HD float ftgp_march_one(const uint16_t* field, int W, int H, float eps, float pu, float pv, float du, float dv, const int32_t* sector_tab = nullptr)
 {
     const int fstride = W + 2;
     const uint32_t plane256 = ftgp_plane256(W, H);
-    FtgpRay r; ftgp_ray_init(r, pu, pv, du, dv, fabsf(1.0f / du), fabsf(1.0f / dv), W, H, fstride, plane256);
+    FtgpRay r; ftgp_ray_init(r, pu, pv, du, dv, fabsf(1.0f / du), fabsf(1.0f / dv), W, H, fstride, plane256, false, sector_tab);
     uint32_t w = FTGP_FIELD_OUT;
     for (int guard = 0; guard < 4 * 8192; ++guard) {
-        w = field[(uint32_t)ftgp_ray_offset(r) >> 1];      // byte offsets are 32-bit unsigned (ftgp_create keeps the field below 4 GiB)
+        w = field[(uint32_t)(guard == 0 ? ftgp_ray_offset_first(r) : ftgp_ray_offset(r)) >> 1];      // byte offsets are 32-bit unsigned (ftgp_create keeps the field below 4 GiB)
         FtgpStep st;
         const bool near = ftgp_ray_step(r, w, eps, st);
         const int t = near ? ftgp_ray_fix(r, st) : st.t;

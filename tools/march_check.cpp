@@ -24,7 +24,7 @@ static float plain(const FtgpTrack& t, float pu, float pv, float du, float dv)
 
 int main(int argc, char** argv)
 {
-    if (argc < 2) { fprintf(stderr, "usage: march_check track.raw [n_rays] [seed] [scale]\n"); return 2; }
+    if (argc < 2) { fprintf(stderr, "usage: march_check track.raw [n_rays] [seed] [scale] [coarse sectors]\n"); return 2; }
     FILE* f = fopen(argv[1], "rb"); if (!f) { perror("open"); return 2; }
     int32_t hdr[3]; if (fread(hdr, 4, 3, f) != 3) return 2;
     std::vector<uint32_t> bits((size_t)hdr[1] * hdr[2]);
@@ -49,6 +49,20 @@ int main(int argc, char** argv)
                 if ((e == 0) != wall_at(t, x, y) || (e != 0 && (e & 255u) == 0)) ++gw_bad;      // 0 <=> wall; a free cell never carries kx = 0
             }
     printf("grid_wall: %ld mismatching pixels\n", gw_bad);
+    // argv[5] = a coarse sector count (8, 16, 32): the field as ftgp_create lays it out for large batches -- all FTGP_SECTORS planes for a ray's
+    // FIRST look-up, then `coarse` planes for every other one -- and the sector table that maps a ray's sector to the two
+    const int coarse = argc > 5 ? atoi(argv[5]) : 0;
+    int32_t tab[FTGP_SECTORS][4];
+    if (coarse) {
+        const int planes = ftgp_sector_table(tab, coarse, true, W + 2, ftgp_plane256(W, H));
+        field.resize(cells * (size_t)planes, (uint16_t)FTGP_FIELD_OUT);
+        #pragma omp parallel for collapse(2) schedule(dynamic, 16)
+        for (int oct = 0; oct < coarse; ++oct)
+            for (int y = 0; y < H; ++y)
+                for (int x = 0; x < W; ++x)
+                    field[(size_t)(FTGP_SECTORS + oct) * cells + (size_t)(y + 1) * (W + 2) + (x + 1)] = (uint16_t)ftgp_box_entry(g.runx.data(), g.runy.data(), W, H, x, y, oct, coarse / 8);
+        printf("two plane sets: %d + %d\n", FTGP_SECTORS, coarse);
+    }
     const float eps = ftgp_snap_eps(W, H);
     std::mt19937_64 rng(seed);
     std::uniform_real_distribution<double> ux(0, t.width), uy(0, t.height), ua(0, 2 * M_PI), u01(0, 1);
@@ -64,7 +78,7 @@ int main(int argc, char** argv)
         float du = (float)(cos(a) * scale), dv = (float)(sin(a) * scale);
         if (kind == 3 || kind == 4) { if (fabsf(du) < 1e-3f) du = 0.0f; if (fabsf(dv) < 1e-3f) dv = 0.0f; }
         if (kind == 2 && (i & 8)) { du = (float)(int)(du); dv = (float)(int)dv; if (du == 0 && dv == 0) du = 1; }
-        const float a_ = ftgp_march_one(field.data(), W, H, eps, pu, pv, du, dv), b_ = plain(t, pu, pv, du, dv);
+        const float a_ = ftgp_march_one(field.data(), W, H, eps, pu, pv, du, dv, coarse ? &tab[0][0] : nullptr), b_ = plain(t, pu, pv, du, dv);
         hits += b_ >= 0;
         if (memcmp(&a_, &b_, 4) != 0) {
             if (bad < 10) printf("MISMATCH kind %d pu %.9g pv %.9g du %.9g dv %.9g : grid %.9g plain %.9g\n", kind, pu, pv, du, dv, a_, b_);
