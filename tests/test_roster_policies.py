@@ -124,6 +124,25 @@ def test_gpu_roster_rollout_matches_the_oracle(product, oracle, name, roster, ra
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(n_rays=90, lidar_mode="fakelidar"), dict(n_rays=1081), dict(n_rays=36, lap_target=1)])
+def test_gpu_roster_in_the_other_kernels_and_shapes(product, oracle, kw):
+    """The roster through the FAKELIDAR kernel, with an odd ray count (no opposite-ray pairs), and to the end of a one-lap race
+    (finished cars fall back to the null driver, custom.py:1446): GPU against oracle."""
+    t = load_track("small-circle" if "lap_target" in kw else "track")
+    kw = dict(n_envs=12, cars_per_env=3, spawn_mode=0, seed=2, **kw)
+    with capi.Env(product, t, **kw) as g, capi.Env(oracle, t, **kw) as o:
+        oracle.dll.oracle_set_threads(o.h, 8)
+        g.set_car_policies(ROSTER); o.set_car_policies(ROSTER)
+        for n in (1, 99, 1400 if "lap_target" in kw else 200):
+            g.rollout("per_car", n); o.rollout("per_car", n)
+            np.testing.assert_array_equal(g.lidar(), o.lidar())
+            np.testing.assert_array_equal(g.ctrl(), o.ctrl())
+            np.testing.assert_array_equal(g.progress(), o.progress())
+            np.testing.assert_array_equal(g.winners(), o.winners())
+        assert g.kernel_name().endswith(", true>")
+
+
+@pytest.mark.gpu
 def test_gpu_single_driver_roster_equals_the_single_policy_launch(product):
     """A roster of one driver is the single-policy launch: same kernel, same bits (and the cover table of the right driver)."""
     t = load_track("track")
