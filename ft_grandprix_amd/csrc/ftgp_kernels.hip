@@ -1,25 +1,27 @@
 // ftgp_kernels.hip -- HIP kernels of the ft_grandprix hot path for gfx950 (CDNA4, wave64).
 //
-//   ftgp_step_kernel<MULTI>   n_steps per launch; one workgroup = whole envs, up to 16 cars on up to 16 waves (the headline shape
-//       is 8 cars on 16 waves, two workgroups per CU), persistent over all steps.  ONE workgroup barrier per step.  Inside a
+//   ftgp_step_kernel<MULTI, FAKE, ROSTER>   n_steps per launch; one workgroup = whole envs, up to 16 cars on up to 16 waves (the headline
+//       shape is 8 cars on 16 waves, two workgroups per CU), persistent over all steps.  ONE workgroup barrier per step.  Inside a
 //       step, concurrently:
-//         K5       waves 0 .. cars-1, one car each: the driver on the car's PREVIOUS scan (the other LDS scan buffer) -> controls;
-//                  before it edits the scan window the wave flushes it to HBM as whole float4 groups (window_flush)
+//         K5       waves 0 .. cars-1, one car each: the driver on the car's PREVIOUS scan (the other LDS scan buffer) -> controls
 //         K1 + K3  the wave whose driver delivers last: integrate + lap progress for ALL cars of the workgroup on four lanes per
 //                  car (dynamics_lanes), then the LiDAR frames of the NEXT step into the other frame buffer
-//         K2       every wave, as soon as its driver work is done: the sweep of THIS step.  The rays of all cars form one pool
-//                  (cars x n_rays); lanes take rays from it in index order and a wave refills its free lanes in batches, so no
-//                  lane waits for another car's slowest ray.
+//         K2       every wave, as soon as its driver work is done: the sweep of THIS step in groups of 64 neighbouring rays of one car
+//                  (lidar_groups): a wave draws a task -- a group, or a group and the same rays turned round --, sets the rays up,
+//                  marches them until all have finished (march_all, hand-written) and delivers the 64 ranges: one 256-byte segment of
+//                  the car's row in HBM, the drivers' window also into the LDS scan buffer.  (-DFTGP_SWEEP_V1: round 3's single pool of
+//                  rays with batched refills, lidar_pool, kept for the diagnostics that were measured on it.)
 //       The sweep reads the LiDAR frames, never the live state, and the scan a driver sees lags the pose by one step
 //       (custom.py:1395-1425): that is what makes the overlap legal.
-//       Staged into LDS once per launch with coalesced 16-B loads: parameter block, vehicle constants, centre-line, ray table,
-//       the cars' state records and the scan windows the drivers read.  The march reads the sector box field from L2
-//       (ftgp_march.h); the rear quarter of a scan goes to HBM ray by ray (4-byte stores that merge in L2).
+//       Staged into LDS once per launch, in one pass, from an image laid out as the LDS is: parameter block, vehicle constants,
+//       centre-line, ray table, cover tables; then the cars' state records and the scan windows the drivers read.  The march reads the
+//       sector box field from L2 (ftgp_march.h).  FAKE: K2 is the reference's own 2-D LiDAR (lidar_fake).  ROSTER: every car slot its own driver.
+//       The end-of-launch metrics record is part of the kernel (launch_metrics).
 //   ftgp_policy_kernel    K5 alone (ftgp_policy_eval).
 //   ftgp_reset_kernel     K4 reset / spawn (+ K3 at the spawn pose), one car per lane.
 //   ftgp_progress_kernel  K3 alone (after ftgp_set_pose), one car per lane.
 //   ftgp_fakelidar_kernel raycast.fakelidar restated, one ray per lane.
-//   ftgp_box_field_kernel the sector box field at create.
+//   ftgp_box_field_kernel the sector box field at create; ftgp_edt_kernel the distance transform of FAKELIDAR mode.
 //   ftgp_metrics_kernel   per-GPU metrics record.
 //
 // Reference behaviour restated by each block is cited inline (paths relative to the reference repo).
@@ -132,10 +134,11 @@ __device__ __forceinline__ Lds lds_view(const LdsOffsets& o, unsigned char* lds)
 // template/mushr.em.xml:98-117 -- ray j leaves the ring at centre - 0.03*dir_j, dir_j = R(yaw) * (sin phi_j, -cos phi_j);
 // j = 0 is the rear, CCW.  Values replace data.sensordata[vehicle_state.sensors] (custom.py:1395).
 //
-// Scheduling: pool index g = car slot * n_rays + j.  A lane marches one ray at a time with ftgp_ray_step/fix/commit (a
-// finished ray idles -- no load, nothing held: the loop body has no active-lane predication); as soon as FTGP_REFILL lanes
-// of the wave are finished, their ranges are stored and they take the next rays of the pool together (one LDS atomic
-// per refill, rank among the free lanes via ballot/popcount).  Which lane marches which ray has no influence on any result.
+// Scheduling: lidar_groups() below -- groups of 64 neighbouring rays, march_all().  What follows first is round 3's sweep (lidar_pool,
+// compiled only with -DFTGP_SWEEP_V1 for the diagnostics measured on it): pool index g = car slot * n_rays + j; a lane marches one ray at
+// a time with ftgp_ray_step/fix/commit (a finished ray idles -- no load, nothing held: the loop body has no active-lane predication); as
+// soon as FTGP_REFILL lanes of the wave are finished, their ranges are stored and they take the next rays of the pool together (one LDS
+// atomic per refill, rank among the free lanes via ballot/popcount).  Which lane marches which ray has no influence on any result.
 #ifndef FTGP_PAD_ASM
 #define FTGP_PAD_ASM "v_add_u32 %0, %0, %3"
 #endif
@@ -1446,7 +1449,8 @@ __device__ __forceinline__ void policy_apply(const DeviceParams& P, const Driver
 // for them and draws a ticket (relaxed agent-scope fetch_add); the workgroup that draws the last ticket takes an agent-scope
 // acquire fence, waits, passes a barrier and reads the records.  (A release fence per workgroup instead -- an L2 write-back
 // each -- cost 14 us per launch, as much as the separate kernel.  Tickets in two levels -- eight per-XCD counters, then a top one --
-// changed nothing: the 7 us this costs per launch are the tail of the last workgroup, not the 512 atomics on one word.)
+// changed nothing: what this costs per launch -- 5 us since the reductions are DPP moves and the last workgroup reads the records with one
+// thread each -- is three dependent trips to memory (the record's stores, the ticket, the last workgroup's read), not the 512 atomics on one word.)
 __device__ __forceinline__ double wave_sum_f64(double v)
 {
     #pragma unroll
