@@ -176,3 +176,33 @@ def test_gpu_runner_takes_the_reference_roster_to_the_device(product, tmp_path, 
     for label, row in zip(("red car", "orange car", "green car"), prog[:3]):
         line = next(x for x in out.splitlines() if label in x)
         assert f"laps {int(row[0]):3d}" in line
+
+
+@pytest.mark.gpu
+def test_gpu_full_size_roster_and_fakelidar_properties(product, oracle):
+    """At BASELINE's batch size: the reference's roster (4096 envs x 3 cars, every car its own driver on the device) and the FAKELIDAR mode
+    (1024 envs) -- launch-split invariance of everything, range sanity, the oracle on a prefix of the envs, the metrics record."""
+    for name, kw, roster, steps, prefix in (
+            ("track", dict(n_envs=4096, cars_per_env=3, n_rays=1080, spawn_mode=0, seed=1234, lap_target=3), ROSTER, 60, 4),
+            ("circle", dict(n_envs=1024, cars_per_env=3, n_rays=360, spawn_mode=0, seed=7, lidar_mode="fakelidar"), ROSTER, 90, 8)):
+        t = load_track(name)
+        with capi.Env(product, t, **kw) as g, capi.Env(product, t, **kw) as g2, capi.Env(oracle, t, **dict(kw, n_envs=prefix)) as o:
+            oracle.dll.oracle_set_threads(o.h, 8)
+            for e in (g, g2, o):
+                e.set_car_policies(roster)
+            g.rollout("per_car", steps); g2.rollout("per_car", steps // 3); g2.rollout("per_car", steps - steps // 3); o.rollout("per_car", steps)
+            r = g.lidar()
+            np.testing.assert_array_equal(r, g2.lidar())
+            np.testing.assert_array_equal(g.pose(), g2.pose())
+            np.testing.assert_array_equal(g.ctrl(), g2.ctrl())
+            np.testing.assert_array_equal(g.progress(), g2.progress())
+            assert ((r == -1) | ((r >= 0) & (r < 60))).all()
+            n = prefix * 3
+            np.testing.assert_array_equal(r[:n], o.lidar())
+            np.testing.assert_array_equal(g.ctrl()[:n], o.ctrl())
+            np.testing.assert_array_equal(g.progress()[:n], o.progress())
+            m = g.metrics_local()
+            assert m[0] == kw["n_envs"] * steps and m[1] == g.n_cars
+            # the two nidc cars and the fast car do not drive alike
+            c = g.ctrl().reshape(kw["n_envs"], 3, 2)
+            assert not np.array_equal(c[:, 0], c[:, 1])
