@@ -96,7 +96,7 @@ def cpu_share():
     return n
 
 
-def cpu_baseline(track, n_rays, policy, cars, seed, budget_s=14.0):
+def cpu_baseline(track, n_rays, policy, cars, seed, budget_s=14.0, lidar_mode="rangefinder"):
     """The CPU oracle ("port") on bounded samples of the same workload on this host (rank 0, N = 1 only), as SURVEY.md 8d
     asks: ONE thread, and all the host cores this process may use (OpenMP over envs) -- plus every logical CPU of the host
     when the process's share is smaller than that.  About `budget_s` seconds of CPU work in all."""
@@ -113,7 +113,7 @@ def cpu_baseline(track, n_rays, policy, cars, seed, budget_s=14.0):
     runs = []
     for threads in legs:
         n_envs = max(8, min(4096, 8 * threads))                    # the first n_envs envs of the batch; >= 8 per thread
-        with capi.Env(ora, track, n_envs=n_envs, cars_per_env=cars, n_rays=n_rays, spawn_mode=1, seed=seed) as o:
+        with capi.Env(ora, track, n_envs=n_envs, cars_per_env=cars, n_rays=n_rays, spawn_mode=1, seed=seed, lidar_mode=lidar_mode) as o:
             ora.dll.oracle_set_threads(o.h, threads)
             t0 = time.perf_counter()
             o.rollout(policy, 10)                                    # calibration
@@ -331,7 +331,8 @@ def main():
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32 rays + f64 state", "data": "synthetic",
             "config": {"workload": f"{args.envs_per_gpu} envs/GPU x {args.cars} car(s), {args.track} track blob, "
-                                   f"{args.rays}-ray LiDAR, {args.policy} driver on device ({baseline_config(args, world)})",
+                                   f"{args.rays}-ray LiDAR, {args.policy} driver on device ({baseline_config(args, world)})"
+                                   + ("" if args.lidar == "rangefinder" else "; FAKELIDAR mode (raycast.py:5-21 as the K2 of the loop), not a BASELINE config"),
                        "envs_per_gpu": args.envs_per_gpu, "n_rays": args.rays, "cars_per_env": args.cars,
                        "policy": args.policy, "steps_per_launch": args.steps, "parallelism": f"env-shard x{world}"},
             "roofline": roof,
@@ -339,7 +340,7 @@ def main():
                                   "sum_steps": float(metrics[:, 0].sum())},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(track, args.rays, args.policy, args.cars, seed)
+            out["cpu_baseline"] = cpu_baseline(track, args.rays, args.policy, args.cars, seed, lidar_mode=args.lidar)
         print(json.dumps(out), flush=True)
     exchange.close()
     if rdzv_x is not None:
