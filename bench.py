@@ -48,7 +48,7 @@ def kernel_source_sha():
     """Identity of the kernel sources a committed counter file was measured on."""
     h = hashlib.sha256()
     for rel in ("ft_grandprix_amd/csrc/ftgp_kernels.hip", "ft_grandprix_amd/csrc/ftgp_march.h", "ft_grandprix_amd/csrc/ftgp_device.h",
-                "ft_grandprix_amd/csrc/ftgp_api.hip", "include/ftgp.h"):
+                "ft_grandprix_amd/csrc/ftgp_api.hip", "ft_grandprix_amd/csrc/diag/ftgp_diag.inc", "include/ftgp.h"):
         with open(os.path.join(ROOT, rel), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]

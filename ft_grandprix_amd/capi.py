@@ -15,7 +15,7 @@ import numpy as np
 
 from .track import Track
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 PATH_POINTS = 100
 MAX_LAP_TIMES = 32
 SNAPSHOT_DOUBLES = 10
@@ -75,7 +75,7 @@ API_SYMBOLS = (
     "rollout", "set_car_policies", "get_lidar", "get_snapshot", "get_pose", "get_progress", "get_winners", "get_lap_times", "get_ctrl",
     "get_steps", "set_pose", "policy_eval", "eval_progress", "metrics_local", "comm_unique_id", "comm_init", "metrics_allgather",
     "metrics_allgather_begin", "metrics_allgather_end", "get_distance_field",
-    "last_kernel_ms", "kernel_name", "fakelidar", "selftest",
+    "last_kernel_ms", "kernel_name", "fakelidar", "selftest", "build_info",
 )
 
 
@@ -143,6 +143,7 @@ class CLib:
             "last_kernel_ms": (i32, [vp, C.POINTER(C.c_float)]),
             "kernel_name": (C.c_char_p, [vp]),
             "selftest": (i32, [i32, C.POINTER(C.c_int64)]),
+            "build_info": (C.c_char_p, []),
         }
         for name, (res, args) in sigs.items():
             if name == "fakelidar" and self.prefix != "ftgp_":
@@ -150,6 +151,11 @@ class CLib:
             if self.has(name):
                 f = self.fn(name)
                 f.restype, f.argtypes = res, args
+
+    def build_info(self) -> dict:
+        """What the library says it was built from and with (ftgp_build_info): {"abi", "sources", "diag", ...}."""
+        text = self.fn("build_info")().decode()
+        return dict(kv.split("=", 1) for kv in text.split() if "=" in kv) | {"diag": text.split("diag=", 1)[1].split(" fair_shift=")[0]}
 
     def last_error(self) -> str:
         s = self.fn("last_error")()

@@ -1097,8 +1097,8 @@ int ftgp_last_kernel_ms(FtgpEnv* e, float* ms)
     return 0;
 }
 
-#ifdef FTGP_STAMPS
-// diagnostic build only: read and clear the phase stamps
+// diagnostic libraries only (-DFTGP_DIAG, csrc/diag/ftgp_diag.inc): read and clear the phase stamps, workgroup tables
+#if defined(FTGP_DIAG) && defined(FTGP_STAMPS)
 int ftgp_debug_stamps(unsigned long long* out)
 {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ftgp_stamps), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
@@ -1106,7 +1106,7 @@ int ftgp_debug_stamps(unsigned long long* out)
     return hipMemcpyToSymbol(HIP_SYMBOL(ftgp_stamps), z, sizeof z) == hipSuccess ? 0 : -1;
 }
 #endif
-#if defined(FTGP_STAMPS) || defined(FTGP_WG_TIMES)
+#if defined(FTGP_DIAG) && defined(FTGP_WG_TIMES)
 int ftgp_debug_set_wg_groups(const int* groups, int n_blocks)      // groups == nullptr: identity
 {
     std::vector<int> g(8192, 0);
@@ -1118,6 +1118,20 @@ int ftgp_debug_wg_times(unsigned long long* out, int n_blocks)
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(ftgp_wg_times), sizeof(unsigned long long) * 4 * (size_t)n_blocks) == hipSuccess ? 0 : -1;
 }
 #endif
+
+// What this library was built from and with: "abi=<n> sources=<hash> diag=<switches|none> fair_shift=<n> waves_per_eu=<n>".  The hash is
+// tools/evidence.py's hash of the kernel sources, handed in by the build (__graft_entry__.build: -DFTGP_BUILD_SOURCES=...); a library
+// built by hand without it says "unstamped".  Touches no device.
+#ifndef FTGP_BUILD_SOURCES
+#define FTGP_BUILD_SOURCES unstamped
+#endif
+#define FTGP_STR2_(x) #x
+#define FTGP_STR_(x) FTGP_STR2_(x)
+const char* ftgp_build_info(void)
+{
+    return "abi=" FTGP_STR_(FTGP_ABI_VERSION) " sources=" FTGP_STR_(FTGP_BUILD_SOURCES) " diag=" FTGP_DIAG_FLAGS
+           " fair_shift=" FTGP_STR_(FTGP_FAIR_SHIFT) " waves_per_eu=" FTGP_STR_(FTGP_WAVES_PER_EU);
+}
 
 int ftgp_selftest(int device_id, int64_t* mismatches)
 {

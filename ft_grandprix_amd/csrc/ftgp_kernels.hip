@@ -9,8 +9,7 @@
 //         K2       every wave, as soon as its driver work is done: the sweep of THIS step in groups of 64 neighbouring rays of one car
 //                  (lidar_groups): a wave draws a task -- a group, or a group and the same rays turned round --, sets the rays up,
 //                  marches them until all have finished (march_all, hand-written) and delivers the 64 ranges: one 256-byte segment of
-//                  the car's row in HBM, the drivers' window also into the LDS scan buffer.  (-DFTGP_SWEEP_V1: round 3's single pool of
-//                  rays with batched refills, lidar_pool, kept for the diagnostics that were measured on it.)
+//                  the car's row in HBM, the drivers' window also into the LDS scan buffer.
 //       The sweep reads the LiDAR frames, never the live state, and the scan a driver sees lags the pose by one step
 //       (custom.py:1395-1425): that is what makes the overlap legal.
 //       Staged into LDS once per launch, in one pass, from an image laid out as the LDS is: parameter block, vehicle constants,
@@ -45,7 +44,7 @@ struct Lds {
     int64_t* steps;
     float* scan;              // [2][cars_per_block][win_floats] scan windows (layout: scan_window_* below), double-buffered by step parity
     int* list;                // [waves_per_block][64] driver scratch
-    int* pool;                // [2] next ray group (lidar_groups) / next ray (lidar_pool) of the sweep, [2] drivers finished, [2] "some LiDAR frame is
+    int* pool;                // [2] next ray group of the sweep (lidar_groups), [2] drivers finished, [2] "some LiDAR frame is
                               // not known to lie well inside the image" (frame_write) -- all double-buffered by step parity
     Force* terms;             // [cars_per_block][FTGP_FORCE_TERMS] K1 staging: force terms in the order they are summed
     double* wnew;             // [cars_per_block][4] K1 staging: new wheel spins
@@ -134,20 +133,7 @@ __device__ __forceinline__ Lds lds_view(const LdsOffsets& o, unsigned char* lds)
 // template/mushr.em.xml:98-117 -- ray j leaves the ring at centre - 0.03*dir_j, dir_j = R(yaw) * (sin phi_j, -cos phi_j);
 // j = 0 is the rear, CCW.  Values replace data.sensordata[vehicle_state.sensors] (custom.py:1395).
 //
-// Scheduling: lidar_groups() below -- groups of 64 neighbouring rays, march_all().  What follows first is round 3's sweep (lidar_pool,
-// compiled only with -DFTGP_SWEEP_V1 for the diagnostics measured on it): pool index g = car slot * n_rays + j; a lane marches one ray at
-// a time with ftgp_ray_step/fix/commit (a finished ray idles -- no load, nothing held: the loop body has no active-lane predication); as
-// soon as FTGP_REFILL lanes of the wave are finished, their ranges are stored and they take the next rays of the pool together (one LDS
-// atomic per refill, rank among the free lanes via ballot/popcount).  Which lane marches which ray has no influence on any result.
-#ifndef FTGP_PAD_ASM
-#define FTGP_PAD_ASM "v_add_u32 %0, %0, %3"
-#endif
-#ifndef FTGP_FIELD_LOAD_MOD
-#define FTGP_FIELD_LOAD_MOD ""        // cache-policy bits of the field load (A/B in profiles/round3/ab_field_load.log: none is best)
-#endif
-#ifndef FTGP_REFILL
-#define FTGP_REFILL (MULTI ? 60 : 48)     // measured optimum (tools/ab.sh): the multi-car refill also runs the inter-vehicle tests
-#endif
+// Scheduling: lidar_groups() below -- groups of 64 neighbouring rays, march_all().  Which lane marches which ray has no influence on any result.
 // number of set bits of `mask` below this lane
 __device__ __forceinline__ int rank_below(uint64_t mask) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0)); }
 
@@ -218,29 +204,10 @@ __device__ __forceinline__ float ray_vs_car(const VehLds* V, const LidarFrame* b
     return best;
 }
 
-// diagnostic builds only, never in the product.  -DFTGP_STAMPS (tools/stamps.sh): per-phase shader-clock totals over all
-// workgroups and steps (their atomics at the end of a launch cost about a millisecond: long launches only) + what
-// -DFTGP_WG_TIMES alone gives: per workgroup the 100-MHz wall clock at entry and at exit, HW_ID, XCC_ID (tools/wg_spread.py),
-// and a table that says which group of cars a workgroup slot takes (tools/wg_pairing.py; [8191] != 0 switches it on).
-#if defined(FTGP_STAMPS) && !defined(FTGP_WG_TIMES)
-#define FTGP_WG_TIMES
-#endif
-#ifdef FTGP_WG_TIMES
-__device__ unsigned long long ftgp_wg_times[8192][4];
-__device__ int ftgp_wg_group[8192];
-#endif
-#ifdef FTGP_STAMPS
-__device__ unsigned long long ftgp_stamps[16];
-#define STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
-#define STAMP_ADD(slot, dt) stamp_acc[slot] += (unsigned long long)(dt)
-#define STAMP_ARG , unsigned long long* stamp_acc
-#define STAMP_PASS , stamp_acc
-#else
-#define STAMP(var) do {} while (0)
-#define STAMP_ADD(slot, dt) do {} while (0)
-#define STAMP_ARG
-#define STAMP_PASS
-#endif
+// Measurement hooks (phase stamps, workgroup entry / exit times, phases compiled out): all of them live in diag/ftgp_diag.inc and exist only
+// in libraries built with -DFTGP_DIAG by tools/*.sh on the GPU box.  The product build defines none of them (ftgp_build_info() says so,
+// tests/test_capi.py checks it).
+#include "diag/ftgp_diag.inc"
 
 // Two workgroups share a CU, and the hardware arbitrates vector issue by priority first and age second: left alone, the
 // workgroup that was dispatched first wins every contested cycle, finishes a launch ~20 % ahead of its partner and leaves the CU
@@ -253,208 +220,9 @@ __device__ unsigned long long ftgp_stamps[16];
 #endif
 __device__ __forceinline__ void sweep_priority(bool second_half)
 {
-#ifndef FTGP_NO_FAIR
+    if (!FTGP_DIAG_FAIR) return;
     const bool mine = (((uint32_t)__builtin_amdgcn_s_memrealtime() >> FTGP_FAIR_SHIFT) & 1u) != (second_half ? 1u : 0u);
     if (mine) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
-#endif
-}
-
-template <bool MULTI>
-__device__ __forceinline__ void lidar_pool(const DeviceParams& P, ScalarParams G, const Lds& L, const LidarFrame* frames, const PairCull* pairs, float* scan_rows, int* pool,
-                                           int ncars_here, int ci0, bool scan_lds, bool second_half STAMP_ARG)
-{
-    typedef const __attribute__((address_space(1))) unsigned char* global_u8;
-    typedef __attribute__((address_space(1))) float* global_f32;
-    typedef __attribute__((address_space(1))) unsigned char* global_u8w;
-    // wave-uniform constants of the sweep: scalar loads from the parameter block in device memory (scalar_view)
-    const int R = G->n_rays, total = ncars_here * R;
-    const int W = G->width, H = G->height, fstride = G->fstride, stride = G->ranges_stride;
-    const uint32_t plane256 = G->plane256, magic = G->ray_magic;
-    const int eighth = G->eighth, win_floats = G->win_floats;
-    const float isx = G->inv_px_x_f, isy = G->inv_px_y_f, eps = G->snap_eps;
-    const float r0 = sgpr(L.veh->ring_radius_f);
-    const global_u8 field = (global_u8)G->field;
-    const global_f32 ranges = (global_f32)G->ranges + (size_t)ci0 * stride;
-    const int cars_per_env = G->cars_per_env;
-    const int lane = lane_here();
-    const bool all_safe = sgpr(pool[4]) == 0;        // every ray of this sweep starts on the image (frame_write): no test per ray
-
-    // A lane's ray state means nothing until the lane is handed a ray (cj >= 0): a lane without one issues no load and stores
-    // nothing.  So the state starts out as whatever the registers hold (defined for the compiler, no instruction spent) --
-    // all but `result`, which ftgp_ray_init(assume_inside) leaves alone.
-    FtgpRay ray;
-    asm volatile("" : "=v"(ray.pum), "=v"(ray.pvm), "=v"(ray.dum), "=v"(ray.dvm), "=v"(ray.ivx), "=v"(ray.ivy), "=v"(ray.s));
-    asm volatile("" : "=v"(ray.ix), "=v"(ray.iy), "=v"(ray.offC), "=v"(ray.ax), "=v"(ray.ay));
-    ray.result = -1.0f;
-    float dxw, dyw;
-    float s_in;                      // crossing time into the cell of the lane's latest lookup
-    asm volatile("" : "=v"(dxw), "=v"(dyw), "=v"(s_in));
-    int cj = -1;                     // (car slot << 16 | ray) of the ray this lane is marching (or has just finished); -1: none
-    bool done = true;                // the lane's ray sits on its terminal cell (or the lane has none)
-    bool pool_empty = false;         // wave-uniform
-    bool hit = false;                // ... and that cell is a wall (not the ring)
-    uint64_t live_mask = 0;          // lanes whose ray is still on its way (wave-uniform)
-    for (int round = 0; round < (1 << 20); ) {      // (bounded: a safety net, counted on the scalar unit)
-        asm volatile("s_add_i32 %0, %0, 1" : "+s"(round) : : "scc");
-        STAMP(ta);
-        sweep_priority(second_half);
-        // ---- finished rays: store the range ...
-        if (done && cj >= 0) {
-            const int c = cj >> 16, j = cj & 0xffff;
-            float r = hit ? fabsf(s_in) : ray.result;        // ftgp_ray_range()
-            if (MULTI) {
-                // Rays also see the other cars of the env (a9).  One record per env-mate (PairCull, written with the frames) rules a
-                // mate out with a dot product: it can only be touched if it lies in front of the ray and within `cull` of its line.
-                // The exact box / puck tests run for what is left; results are unaffected by the cull.
-                const PairCull* mates = pairs + c * FTGP_PAIR_STRIDE;
-                for (int k = 0; k < cars_per_env; ++k) {
-                    const float4 q = *reinterpret_cast<const float4*>(mates + k);
-                    const float al = fmaf(q.x, dxw, q.y * dyw);
-                    if (al >= q.z) {
-                        const float cull = L.veh->cull_radius;
-                        if (r >= 0.0f && (al + r0) - cull > r) continue;             // the mate lies beyond the wall hit
-                        const LidarFrame* me = frames + c;
-                        const float rc = ray_vs_car(L.veh, frames + me->slot0 + k, q.x, q.y, dxw, dyw);
-                        if (rc < INFINITY && (r < 0.0f || rc < r)) r = rc;
-                    }
-                }
-            }
-            // the on-device drivers read ranges[0] and ranges[eighth : n - eighth]: that window is kept in LDS and goes to HBM as whole
-            // lines once the sweep is over (window_flush); everything else is stored ray by ray (4-byte stores that merge in L2)
-            const int jw = j - eighth;
-            const bool in_window = scan_lds && (unsigned)jw < (unsigned)(R - 2 * eighth);
-            if (!in_window) *(global_f32)((global_u8w)ranges + ((uint32_t)(__mul24(c, stride) + j) << 2)) = r;      // SGPR base + 32-bit lane offset
-            if (scan_lds) {
-                float* row = scan_rows + __mul24(c, win_floats);
-                if (in_window) row[(eighth & 3) + jw] = r;
-                if (j == 0) row[win_floats - 1] = r;
-            }
-            cj = -1;
-        }
-        // ---- ... and take the next rays of the pool: the free lanes get consecutive pool indices base, base + 1, ...
-        if (!pool_empty) {
-            const uint64_t free_mask = ~live_mask;                   // wave-uniform: every lane of the wave is in here
-            const int nfree = __popcll(free_mask);
-            int base = 0;
-            if (lane == 0) base = atomicAdd(pool, nfree);
-            base = __builtin_amdgcn_readfirstlane(base);
-            const int rank = rank_below(free_mask);
-            // pool index -> (car slot, ray): one scalar division for the batch; a batch spans at most two cars when R >= 64
-            int c, j;
-            if (R >= FTGP_WAVE) {
-                const int c0 = (int)__umulhi((uint32_t)base, magic), j0 = base - c0 * R;
-                const int d = j0 + rank - R;                         // >= 0: the ray belongs to the next car
-                const int same = d >> 31;                            // -1 / 0 (adds and shifts: 2-cycle instructions; a compare and a select cost 4 each)
-                c = c0 + 1 + same; j = d + (R & same);
-            } else {
-                c = (int)__umulhi((uint32_t)(base + rank), magic); j = base + rank - c * R;
-            }
-            if (done && base + rank < total) {
-                cj = (c << 16) | j;
-                const float4 f4 = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(frames) + __mul24(c, (int)sizeof(LidarFrame)));   // u0, v0, chf, shf
-                const float2 bd = L.ray[j];
-                dxw = fmaf(f4.z, bd.x, -(f4.w * bd.y));
-                dyw = fmaf(f4.w, bd.x, f4.z * bd.y);
-                const float du = dxw * isx;
-                const float dv = -(dyw * isy);
-                const float pu = fmaf(du, -r0, f4.x);
-                const float pv = fmaf(dv, -r0, f4.y);
-                float ivx, ivy;
-                rcp_abs2(du, dv, ivx, ivy);
-                // `result` stays as set at the top of the sweep (-1); offsets and strides of the ray's sector come out of the LDS table
-                ftgp_ray_init(ray, pu, pv, du, dv, ivx, ivy, W, H, fstride, plane256, true, &P.sector_tab[0][0], G->slice_factor);
-                if (!all_safe) {         // wave-uniform, rare: some car of the workgroup is near the image edge, off it, or has finished
-                    ftgp_ray_park_if_outside(ray, pu, pv, W, H);
-                    // a finished car's rangefinders are switched off (custom.py:1436-1439): its frame carries u0 = -inf, so the ray is
-                    // parked like any ray that starts off the image, and reads 0 instead of -1
-                    ray.result = (f4.x == -INFINITY) ? 0.0f : -1.0f;
-                }
-            }
-            pool_empty = base + nfree >= total;
-        }
-        if (!__any(cj >= 0)) break;      // nothing in flight and nothing left to hand out
-        STAMP(tb); STAMP_ADD(8, tb - ta); STAMP_ADD(9, 1);
-        // ---- march until enough lanes are free to make a batched refill worthwhile (or, at the end, until all are done)
-        const int want = pool_empty ? FTGP_WAVE : FTGP_REFILL;
-        uint32_t w = FTGP_FIELD_OUT;
-        bool alive = cj >= 0;            // lanes whose ray is known to sit on its terminal cell keep that cell's entry and issue no load
-#ifdef FTGP_NO_GUARD
-        for (;;) {
-#else
-        for (int guard = 0; guard < 4 * 8192; ++guard) {
-#endif
-#ifdef FTGP_PAD_SALU        // diagnostic: FTGP_PAD_SALU scalar filler instructions per march iteration -- is the scalar unit a limit?
-            {   int spad = 0;
-                #pragma unroll
-#if !defined(FTGP_PAD_SALU_KIND) || FTGP_PAD_SALU_KIND == 0
-#define FTGP_PAD_SALU_ASM "s_add_u32 %0, %0, 1"
-#elif FTGP_PAD_SALU_KIND == 1
-#define FTGP_PAD_SALU_ASM "s_nop 0"
-#elif FTGP_PAD_SALU_KIND == 2
-#define FTGP_PAD_SALU_ASM "s_and_b64 vcc, vcc, exec"
-#elif FTGP_PAD_SALU_KIND == 3
-#define FTGP_PAD_SALU_ASM "s_waitcnt lgkmcnt(0)"
-#elif FTGP_PAD_SALU_KIND == 4
-#define FTGP_PAD_SALU_ASM "s_cbranch_execz 0"
-#elif FTGP_PAD_SALU_KIND == 5
-#define FTGP_PAD_SALU_ASM "s_mov_b32 %0, 7"
-#endif
-                for (int q = 0; q < FTGP_PAD_SALU; ++q) asm volatile(FTGP_PAD_SALU_ASM : "+s"(spad) : : "scc", "vcc");
-            }
-#endif
-            // a finished ray idles: it issues no load (w keeps its terminal cell's entry, so st.live stays false).  The crossing
-            // time into the cell that is looked up is put aside under the load's mask (s_in: a move where there is a mask anyway)
-            // -- for the lookup that ends the ray that is its range -- and the ray's cell and time, never used again, are left
-            // to drift: no select holds them.  (Running the whole body under the mask of the unfinished lanes instead was
-            // measured 4 % slower: the divergent control flow costs more than the selects it saves.)
-            // (one statement: entry offset = ftgp_ray_offset(), the move, the load -- the compiler pads between separate ones)
-            int off;
-            if (alive) asm volatile("v_mad_i32_i24 %2, %3, %4, %5\n\tv_mad_i32_i24 %2, %6, %7, %2\n\tv_mov_b32 %0, %8\n\t"
-                                    "global_load_ushort %1, %2, %9" FTGP_FIELD_LOAD_MOD "\n\ts_waitcnt vmcnt(0)"
-                                    : "+v"(s_in), "+v"(w), "=&v"(off)
-                                    : "v"(ray.iy), "v"(ray.ay), "v"(ray.offC), "v"(ray.ix), "v"(ray.ax), "v"(ray.s), "s"(field));
-#ifdef FTGP_PAD_EXEC        // diagnostic (tools/half_exec.sh, never in the product): 16 filler instructions per march iteration with all 64 lanes
-            // enabled (FTGP_PAD_EXEC = 0), with lanes 32..63 disabled (1) or with lanes 0..31 disabled (2) -- does a wave64 vector instruction
-            // whose one half is empty issue in one pass instead of two?  The mask is saved, changed and restored INSIDE one asm
-            // statement: nothing the compiler schedules can land between the two writes of exec.  (Round 3's version wrote exec_hi in
-            // separate statements; the compiler moved two instructions of the march -- the SDWA adds that form the box's far corner --
-            // between them, lanes 32..63 kept a stale corner, and the next field load of those lanes faulted.)
-            {   int pad0 = lane, pad1 = lane + 1; int pad_save;
-#define FTGP_PAD_F2 FTGP_PAD_EXEC_ASM("%0") "\n\t" FTGP_PAD_EXEC_ASM("%1") "\n\t"
-#define FTGP_PAD_F16 FTGP_PAD_F2 FTGP_PAD_F2 FTGP_PAD_F2 FTGP_PAD_F2 FTGP_PAD_F2 FTGP_PAD_F2 FTGP_PAD_F2 FTGP_PAD_F2
-#if FTGP_PAD_EXEC == 1
-                asm volatile("s_mov_b32 %2, exec_hi\n\ts_mov_b32 exec_hi, 0\n\t" FTGP_PAD_F16 "s_mov_b32 exec_hi, %2\n\ts_nop 1" : "+v"(pad0), "+v"(pad1), "=&s"(pad_save) : "v"(lane), "s"(live_mask) : "vcc");
-#elif FTGP_PAD_EXEC == 2
-                asm volatile("s_mov_b32 %2, exec_lo\n\ts_mov_b32 exec_lo, 0\n\t" FTGP_PAD_F16 "s_mov_b32 exec_lo, %2\n\ts_nop 1" : "+v"(pad0), "+v"(pad1), "=&s"(pad_save) : "v"(lane), "s"(live_mask) : "vcc");
-#else
-                asm volatile("s_mov_b32 %2, exec_hi\n\ts_nop 0\n\t" FTGP_PAD_F16 "s_nop 0\n\ts_nop 1" : "+v"(pad0), "+v"(pad1), "=&s"(pad_save) : "v"(lane), "s"(live_mask) : "vcc");
-#endif
-            }
-#endif
-#ifdef FTGP_PAD_VALU        // diagnostic (tools/valu_cost.sh): FTGP_PAD_VALU independent filler instructions per march iteration; what one more costs
-            {   int pad0 = lane, pad1 = lane + 1; unsigned long long padm; double padd0 = 1.0, padd1 = 2.0;
-                #pragma unroll
-                for (int q = 0; q < FTGP_PAD_VALU / 2; ++q) {      // %0 scratch VGPR, %1 SGPR pair (write-only), %2 scratch VGPR pair, %3 lane index, %4 SGPR mask
-                    asm volatile(FTGP_PAD_ASM : "+v"(pad0), "=s"(padm), "+v"(padd0) : "v"(lane), "s"(live_mask) : "vcc");
-                    asm volatile(FTGP_PAD_ASM : "+v"(pad1), "=s"(padm), "+v"(padd1) : "v"(lane), "s"(live_mask) : "vcc");
-                }
-            }
-#endif
-            FtgpStep st;
-            const bool near = ftgp_ray_step(ray, w, eps, st);
-            live_mask = __builtin_amdgcn_ballot_w64(st.live);           // here, next to the comparison: the mask is its result
-            int t = st.t;
-            if (__any(near)) { const int tf = ftgp_ray_fix(ray, st); t = near ? tf : t; }
-            ftgp_ray_commit(ray, st, t, false);
-            alive = st.live;
-            STAMP_ADD(11, 1);
-            if (FTGP_WAVE - __popcll(live_mask) >= want) break;
-        }
-        STAMP(tc); STAMP_ADD(10, tc - tb);
-        // a finished ray has just looked its terminal cell up once more: w is that cell's entry
-        done = !alive;
-        hit = w == 0u;
-    }
 }
 
 // The march of one wave's rays until ALL of them sit on their terminal cell: hand-written, because what limits this kernel is the
@@ -597,11 +365,7 @@ __device__ __forceinline__ void lidar_groups(const DeviceParams& P, ScalarParams
             march_all(ray.ix, ray.iy, ray.s, w, ray.pum, ray.pvm, ray.ivx, ray.ivy, ray.dum, ray.dvm, ftgp_ray_offset_first(ray), ray.offC, ray.ax, ray.ay, thr, field);
             STAMP(tc); STAMP_ADD(10, tc - tb); STAMP_ADD(9, 1);
             float r = (w == 0u) ? fabsf(ray.s) : ray.result;
-#ifdef FTGP_ABLATE_MATES      // diagnostic (timing only, wrong results): what the inter-vehicle tests cost
-            if (false) {
-#else
-            if (MULTI) {
-#endif
+            if (MULTI && FTGP_DIAG_RUN_MATES) {
                 // Rays also see the other cars of the env (a9).  One record per env-mate (PairCull, written with the frames) rules a
                 // mate out with a dot product: it can only be touched if it lies in front of the ray and within `cull` of its line.
                 const PairCull* mates = pairs + c * FTGP_PAIR_STRIDE;
@@ -680,7 +444,7 @@ __device__ __forceinline__ void lidar_groups(const DeviceParams& P, ScalarParams
 //   range    (distance / W) * s (custom.py:1392-1393), stored as binary32
 // int() truncates toward zero and a negative index wraps like numpy's; an index past the end -- the reference's IndexError --
 // ends the ray with range -1.  Rays are dealt to lanes statically (this mode is for parity, not for throughput); the ranges go
-// where lidar_pool() puts them: the drivers' window in LDS, everything else straight to HBM.
+// where lidar_groups() puts them: every range to HBM, the drivers' window to LDS as well.
 __device__ __forceinline__ void lidar_fake(ScalarParams G, const LidarFrame* frames, float* scan_rows, int ncars_here, int ci0, bool scan_lds, int wave, int nwaves)
 {
     const int R = G->n_rays, total = ncars_here * R, W = G->width, H = G->height, stride = G->ranges_stride;
@@ -725,27 +489,6 @@ __device__ __forceinline__ void lidar_fake(ScalarParams G, const LidarFrame* fra
             if (in_window) row[(eighth & 3) + jw] = r;
             if (j == 0) row[win_floats - 1] = r;
         }
-    }
-}
-
-// The scan window of a car (LDS row, see scan_window_first) to its row in HBM, by one wave: whole float4 groups -- 16 bytes per
-// lane, whole 128-byte lines per 8 lanes -- and single floats only at the two ragged ends of the window.
-template <class PP>
-__device__ __forceinline__ void window_flush(PP P, const float* __restrict__ row, int ci)
-{
-    typedef __attribute__((address_space(1))) float* global_f32;
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
-    typedef __attribute__((address_space(1))) f32x4* global_f32x4;
-    const int eighth = sgpr(P->eighth), n = sgpr(P->n_rays) - 2 * eighth, w0 = eighth & 3;
-    // LDS float index q <-> HBM float index (eighth - w0) + q of the car's row; the window is q in [w0, w0 + n)
-    const global_f32 dst = (global_f32)uniform_ptr(P->ranges) + (size_t)ci * sgpr(P->ranges_stride) + (eighth - w0);
-    const int lane = lane_here();
-    const int g0 = w0 ? 1 : 0, g1 = (w0 + n) >> 2;                   // float4 groups [g0, g1) lie entirely inside the window
-    for (int g = g0 + lane; g < g1; g += FTGP_WAVE) ((global_f32x4)dst)[g] = reinterpret_cast<const f32x4*>(row)[g];
-    if (lane < 4) {                                                  // the ragged ends: floats [w0, 4) of group 0 and [4 * g1, w0 + n)
-        if (w0 && lane >= w0 && lane < w0 + n) dst[lane] = row[lane];
-        const int q = 4 * g1 + lane;
-        if (q < w0 + n && q >= 4 * g0) dst[q] = row[q];
     }
 }
 
@@ -981,7 +724,7 @@ __device__ __forceinline__ bool frame_write(const DeviceParams& P, const FtgpVeh
     const double lcy = st->y + (sh * v.lidar_x + ch * v.lidar_y);
     const int finished = st->finished;
     const float u0 = (float)((lcx - P.origin_x) * P.inv_px_x), v0 = (float)((P.origin_y - lcy) * P.inv_px_y);
-    fr->u0 = finished ? -INFINITY : u0;                       // -inf: rangefinders switched off (see lidar_pool)
+    fr->u0 = finished ? -INFINITY : u0;                       // -inf: rangefinders switched off (see lidar_groups)
     fr->v0 = v0;
     fr->chf = (float)ch; fr->shf = (float)sh;
     fr->lcx = lcx; fr->lcy = lcy;
@@ -1596,15 +1339,7 @@ __global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(cons
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = __builtin_amdgcn_readfirstlane(blockDim.x >> 6);
-#ifdef FTGP_WG_TIMES
-    if (threadIdx.x == 0 && blockIdx.x < 8192) {
-        ftgp_wg_times[blockIdx.x][0] = __builtin_amdgcn_s_memrealtime();
-        unsigned hw, xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        ftgp_wg_times[blockIdx.x][2] = hw; ftgp_wg_times[blockIdx.x][3] = xcc;
-    }
-#endif
+    FTGP_DIAG_WG_ENTER();
     // The parameter block itself goes to LDS (later reads come from there, not from ~70 pinned SGPRs), with the vehicle constants, the centre
     // line, the fan and the driver's cover table: ONE image in HBM laid out as the LDS is (ftgp_create), so that a thread's loads are all in
     // flight together -- the launch pays one memory latency here, not one per table.
@@ -1626,11 +1361,7 @@ __global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(cons
     __syncthreads();
     const LdsOffsets off = lds_offsets(P0);
     const int cpb = sgpr(P0.cars_per_block);
-#ifdef FTGP_WG_TIMES
-    const int ci0 = (ftgp_wg_group[8191] && blockIdx.x < 8191 ? __builtin_amdgcn_readfirstlane(ftgp_wg_group[blockIdx.x]) : (int)blockIdx.x) * cpb;
-#else
-    const int ci0 = (int)blockIdx.x * cpb;
-#endif
+    const int ci0 = FTGP_DIAG_WG_GROUP((int)blockIdx.x) * cpb;
     const int ncars_here = min(cpb, sgpr(P0.n_cars) - ci0);
     const bool second_half = (((int)blockIdx.x / max(1, sgpr(P0.n_cu))) & 1) != 0;      // see sweep_priority(): workgroups b and b + n_cu share a CU in the first dispatch wave
     const bool need_scan = (policy == FTGP_POLICY_NIDC || policy == FTGP_POLICY_FAST || (ROSTER && policy == FTGP_POLICY_PER_CAR));
@@ -1675,9 +1406,7 @@ __global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(cons
     //   every wave         K2: the sweep of THIS step from the current frame buffer (as soon as its driver work is done)
     // The scan a driver sees lags the pose by one step (custom.py:1395-1425), which is what makes this legal: the sweep of
     // step t needs only the pose of step t, and that depends on the controls of step t-1.
-#ifdef FTGP_STAMPS
-    unsigned long long stamp_acc[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-#endif
+    STAMP_DECLARE();
     for (int it = 0; it < n_steps; ++it) {
         STAMP(t0);
         // Each phase of a step fetches what it needs of the parameter block with scalar loads (scalar_view) and sees the LDS arrays
@@ -1691,14 +1420,9 @@ __global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(cons
             const int win_floats = G->win_floats;
             LidarFrame* next_frames = L.frame + (par ^ 1) * cpb;
             float* scan_prev = L.scan + (par ^ 1) * cpb * win_floats;
-#ifndef FTGP_NO_PRIO
             // the driver -> dynamics chain is the latency-critical path of a step and a small share of its instructions: let it issue first
-            __builtin_amdgcn_s_setprio(3);
-#endif
+            if (FTGP_DIAG_PRIO) __builtin_amdgcn_s_setprio(3);
             for (int c = wave; c < ncars_here; c += nwaves) {
-#ifdef FTGP_SWEEP_V1
-                if (!FAKE && need_scan && it > 0) window_flush(G, scan_prev + c * win_floats, ci0 + c);     // the previous sweep's window, before the driver edits it
-#endif
                 if (ROSTER && policy == FTGP_POLICY_PER_CAR) {
                     // the roster's drivers: car slot c of the workgroup has its own (wave-uniform: a scalar load); both cover tables are staged
                     const int pol = G->car_policy[c];
@@ -1716,51 +1440,36 @@ __global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(cons
                 STAMP(t1); STAMP_ADD(0, t1 - t0);
                 if (n == ncars_here - 1) {            // every driver of the workgroup has delivered its controls
                     if (lane_here() == 0) { L.pool[par ^ 1] = 0; L.pool[2 + (par ^ 1)] = 0; }     // the next step's counters (idle during this step)
-#ifndef FTGP_ABLATE_K1
-                    dynamics_lanes<MULTI>(P, L, next_frames, L.pairs + (par ^ 1) * cpb * FTGP_PAIR_STRIDE, L.mmask + (par ^ 1) * cpb * G->mmask_stride, &G->group_order[0],
-                                          L.pool + 4 + (par ^ 1), ncars_here, ci0);
-#endif
+                    if (FTGP_DIAG_RUN_K1)
+                        dynamics_lanes<MULTI>(P, L, next_frames, L.pairs + (par ^ 1) * cpb * FTGP_PAIR_STRIDE, L.mmask + (par ^ 1) * cpb * G->mmask_stride, &G->group_order[0],
+                                              L.pool + 4 + (par ^ 1), ncars_here, ci0);
                     STAMP(t2); STAMP_ADD(2, t2 - t1); STAMP_ADD(7, 1);
                 }
             }
-#ifndef FTGP_NO_PRIO
-            __builtin_amdgcn_s_setprio(0);
-#endif
+            if (FTGP_DIAG_PRIO) __builtin_amdgcn_s_setprio(0);
         }
         STAMP(t3);
-#ifndef FTGP_ABLATE_K2
-        {
+        if (FTGP_DIAG_RUN_K2) {
             const ScalarParams G = scalar_view(Pg);
             const LdsOffsets off = lds_offsets(G);
             const DeviceParams& P = *reinterpret_cast<const DeviceParams*>(lds + off.params);
             const Lds L = lds_view(off, lds);
             if (FAKE) lidar_fake(G, L.frame + par * cpb, L.scan + par * cpb * G->win_floats, ncars_here, ci0, need_scan, wave, nwaves);
-#ifdef FTGP_SWEEP_V1
-            else lidar_pool<MULTI>(P, G, L, L.frame + par * cpb, L.pairs + par * cpb * FTGP_PAIR_STRIDE, L.scan + par * cpb * G->win_floats, L.pool + par, ncars_here, ci0, need_scan, second_half STAMP_PASS);
-#else
             else lidar_groups<MULTI>(P, G, L, L.frame + par * cpb, L.pairs + par * cpb * FTGP_PAIR_STRIDE, L.mmask + par * cpb * G->mmask_stride, L.scan + par * cpb * G->win_floats,
                                      L.pool + par, ncars_here, ci0, need_scan, second_half STAMP_PASS);
-#endif
         }
-#endif
         STAMP(t4);
         __syncthreads();
         STAMP(t5);
         STAMP_ADD(3, t4 - t3); STAMP_ADD(4, t5 - t4); STAMP_ADD(5, 1); STAMP_ADD(6, t5 - t0);
     }
 
-#ifdef FTGP_STAMPS
-    if (lane_here() == 0) for (int q = 0; q < 12; ++q) atomicAdd(&ftgp_stamps[q], stamp_acc[q]);
-#endif
+    STAMP_FLUSH();
     const DeviceParams& P = P0;
     const LdsOffsets off_end = lds_offsets(scalar_view(Pg));
     const Lds L = lds_view(off_end, lds);
     for (int c = wave; c < ncars_here; c += nwaves) {
         const int ci = ci0 + c;
-#ifdef FTGP_SWEEP_V1
-        if (!FAKE && need_scan && n_steps > 0)          // the last sweep's window
-            window_flush(&P, L.scan + (((n_steps - 1) & 1) * cpb + c) * P.win_floats, ci);
-#endif
         if (lane_here() < (int)(sizeof(CarCore) / 4))
             reinterpret_cast<uint32_t*>(static_cast<CarCore*>(&P.cars[ci]))[lane_here()] = reinterpret_cast<const uint32_t*>(L.cars + c)[lane_here()];
         if (lane_here() == 0 && ci % P.cars_per_env == 0) P.steps[ci / P.cars_per_env] = L.steps[c];
@@ -1769,10 +1478,7 @@ __global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(cons
         __syncthreads();
         launch_metrics(P, L.cars, L.steps, ncars_here, ci0, lds + P.off_scan, reinterpret_cast<double*>(lds + P.off_path), metrics_slot, wave);
     }
-#ifdef FTGP_WG_TIMES
-    __syncthreads();
-    if (threadIdx.x == 0 && blockIdx.x < 8192) ftgp_wg_times[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
-#endif
+    FTGP_DIAG_WG_EXIT();
 }
 
 template __global__ void ftgp_step_kernel<false, false, false>(const DeviceParams*, int, int, int);

@@ -293,7 +293,7 @@ struct FtgpStep { float sn; int t, xe, ye; bool stepx, live; };       // live: t
 // landing point is within `eps` of a pixel boundary: the caller then runs ftgp_ray_fix() before ftgp_ray_commit().
 // Otherwise the estimate needs no clamp: the ray leaves the box through the edge it reaches first, i.e. at a transverse
 // coordinate inside the box's span, and the estimate is off by far less than eps.
-// Vector instructions are chosen by what they cost on gfx950 (tools/valu_cost.sh): add / logic / shift / mov and binary32
+// Vector instructions are chosen by what they cost on gfx950 (profiles/round2/valu_cost.log): add / logic / shift / mov and binary32
 // add / mul / fma issue in 2 cycles per wave, everything else used here (selects, compares, conversions, 24-bit multiplies,
 // three-operand integer forms, fract) in 4.
 FTGP_HD bool ftgp_ray_step(const FtgpRay& r, uint32_t w, float eps, FtgpStep& st)

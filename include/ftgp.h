@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FTGP_ABI_VERSION 4
+#define FTGP_ABI_VERSION 5
 
 /* status codes */
 #define FTGP_OK              0
@@ -311,6 +311,11 @@ int ftgp_last_kernel_ms(FtgpEnv *env, float *ms);
 
 /* Name of the kernel that ftgp_rollout/ftgp_step launches for the current configuration (for rocprof matching). */
 const char *ftgp_kernel_name(FtgpEnv *env);
+
+/* What the loaded library was built from and with (no reference counterpart; touches no device):
+ * "abi=<n> sources=<hash of the kernel sources, tools/evidence.py sha> diag=<diagnostic switches, "none" in the product> fair_shift=<n>
+ * waves_per_eu=<n>".  __graft_entry__.build() rebuilds a library whose hash is not the tree's; tests/test_capi.py checks both fields. */
+const char *ftgp_build_info(void);
 
 #ifdef __cplusplus
 }

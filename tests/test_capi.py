@@ -27,6 +27,23 @@ def test_library_exports_every_declared_symbol(product):
         assert hasattr(product.dll, sym), sym
 
 
+def test_shipped_library_is_the_trees_sources_without_diagnostics(product):
+    """ftgp_build_info: the library under ft_grandprix_amd/lib was built by __graft_entry__.build() from the sources in the tree (their
+    hash, tools/evidence.py sha) and with no diagnostic switch (csrc/diag/ftgp_diag.inc compiles every hook out)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        from evidence import sha
+    finally:
+        sys.path.pop(0)
+    info = product.build_info()
+    assert info["abi"] == str(capi.ABI_VERSION)
+    assert info["diag"] == "none", info
+    assert info["sources"] == sha(), "ft_grandprix_amd/lib/libftgp.so was not built from these sources: run __graft_entry__.build()"
+    text = open(os.path.join(ROOT, "ft_grandprix_amd", "csrc", "ftgp_kernels.hip")).read()
+    assert "#ifdef FTGP_" not in text and "#ifndef FTGP_NO" not in text      # hooks live in csrc/diag/ftgp_diag.inc behind -DFTGP_DIAG
+
+
 def test_struct_layouts_match_the_header(product, oracle):
     # both libraries fill FtgpVehicle through the same C struct: identical bytes => identical layout and constants
     a, b = product.default_vehicle(), oracle.default_vehicle()

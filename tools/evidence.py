@@ -11,7 +11,7 @@ import hashlib, json, os, re, shutil, subprocess, sys, tempfile, time
 
 ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 SOURCES = ("ft_grandprix_amd/csrc/ftgp_kernels.hip", "ft_grandprix_amd/csrc/ftgp_march.h", "ft_grandprix_amd/csrc/ftgp_device.h",
-           "ft_grandprix_amd/csrc/ftgp_api.hip", "include/ftgp.h")
+           "ft_grandprix_amd/csrc/ftgp_api.hip", "ft_grandprix_amd/csrc/diag/ftgp_diag.inc", "include/ftgp.h")
 LLVM = "/opt/rocm/lib/llvm/bin"
 
 
