@@ -411,12 +411,7 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
     const long cars_total = (long)cfg->n_envs * cfg->cars_per_env;
     int n_sectors = cars_total >= 8192 ? 8 : cars_total >= 2048 ? 16 : 64;
     if (const char* sv = getenv("FTGP_SECTORS_RT")) { const int c = atoi(sv); if (c == 8 || c == 16 || c == 32 || c == 64) n_sectors = c; }
-    // FTGP_FINE_FIRST=1 (experiment, off by default): the FIRST look-up of every ray served by planes of their own with all 64 sectors.  The
-    // model liked it (the first box is the jump that matters most: 92.0 -> 83.3 wave-iterations per car-step, 64 sectors throughout: 77.1);
-    // the GPU did not (+7 % time on the headline and on config 5, profiles/round4/ab_fine_first.log): 64 start-cell lines per car instead
-    // of 16 are, for the 512 cars an XCD serves, the whole 4-MiB L2.  The mechanism is the sector table, which costs nothing when unused.
-    const bool fine_first = getenv("FTGP_FINE_FIRST") && atoi(getenv("FTGP_FINE_FIRST")) == 1;
-    const int n_planes = (fine_first && n_sectors != FTGP_SECTORS) ? FTGP_SECTORS + n_sectors : n_sectors;
+    const int n_planes = n_sectors;
     // the march addresses the field with a 32-bit byte offset
     if ((uint64_t)ftgp_plane256(t.width, t.height) * 256u * (uint64_t)n_planes > 0xFFFFFFFFull)
         return fail(FTGP_ERR_ARG, "track image too large: the sector box field (2 bytes per pixel and direction sector) must stay below 4 GiB%s");
@@ -466,9 +461,9 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
     P.map_size = cfg->map_size > 0.0 ? cfg->map_size : 40.0;                     // 20 * scale, custom.py:1155,1382
     P.width = t.width; P.height = t.height; P.words_per_row = t.words_per_row; P.fstride = t.width + 2;
     P.plane256 = ftgp_plane256(t.width, t.height);
-    // a ray's sector is always found among all FTGP_SECTORS; the table says which plane serves it at the first look-up and afterwards
+    // a ray's sector is always found among all FTGP_SECTORS; the table says which plane serves it
     P.n_sectors = n_sectors; P.slice_factor = FTGP_SLICE_FACTOR(FTGP_SLOPE_SLICES);
-    P.n_planes = ftgp_sector_table(P.sector_tab, n_sectors, fine_first, t.width + 2, P.plane256);
+    P.n_planes = ftgp_sector_table(P.sector_tab, n_sectors, t.width + 2, P.plane256);
     P.px_size_x = t.px_size_x; P.px_size_y = t.px_size_y; P.origin_x = t.origin_x; P.origin_y = t.origin_y;
     P.inv_px_x = 1.0 / t.px_size_x; P.inv_px_y = 1.0 / t.px_size_y;
     P.inv_px_x_f = (float)P.inv_px_x; P.inv_px_y_f = (float)P.inv_px_y;
@@ -636,12 +631,7 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
         CREATE_TRY(hipMalloc(&d_runy, 2 * plane * sizeof(uint16_t)));
         CREATE_TRY(hipMemcpy(d_runx, tab.runx.data(), 2 * plane * sizeof(uint16_t), hipMemcpyHostToDevice));
         CREATE_TRY(hipMemcpy(d_runy, tab.runy.data(), 2 * plane * sizeof(uint16_t), hipMemcpyHostToDevice));
-        // [all FTGP_SECTORS planes for the first look-up, if they are kept apart |] the n_sectors planes of every other look-up
-        const int fine = P.n_planes - P.n_sectors;
-        if (fine > 0)
-            hipLaunchKernelGGL(ftgp_box_field_kernel, dim3((unsigned)((plane_cells * (size_t)fine + 255) / 256)), dim3(256), 0, e->stream, d_runx, d_runy, t.width, t.height, fine, e->d_field);
-        hipLaunchKernelGGL(ftgp_box_field_kernel, dim3((unsigned)((plane_cells * (size_t)P.n_sectors + 255) / 256)), dim3(256), 0, e->stream, d_runx, d_runy, t.width, t.height, P.n_sectors,
-                           e->d_field + plane_cells * (size_t)fine);
+        hipLaunchKernelGGL(ftgp_box_field_kernel, dim3((unsigned)((plane_cells * (size_t)P.n_sectors + 255) / 256)), dim3(256), 0, e->stream, d_runx, d_runy, t.width, t.height, P.n_sectors, e->d_field);
         CREATE_TRY(hipGetLastError());
         CREATE_TRY(hipStreamSynchronize(e->stream));
         (void)hipFree(d_runx); (void)hipFree(d_runy);

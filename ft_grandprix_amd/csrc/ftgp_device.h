@@ -69,7 +69,7 @@ struct DeviceParams {
     uint32_t plane256;            // bytes per (padded) sector plane of the box field / 256
     int32_t n_sectors;            // direction sectors of this handle's box field: 8 x (1, 2, 4 or 8 slope slices per octant)
     float slice_factor;           // FTGP_SLICE_FACTOR(FTGP_SLOPE_SLICES): a ray's sector is found among all FTGP_SECTORS, sector_tab maps it to planes
-    int32_t n_planes, reserved4;  // planes of the field: n_sectors, or FTGP_SECTORS + n_sectors when the first look-up has planes of its own
+    int32_t n_planes, reserved4;  // planes of the field (= n_sectors)
     int32_t contact_reach;        // chessboard reach (pixels) of the wall-contact window; `nearbits` is the wall set dilated by it
     // step-kernel launch shape and LDS layout (byte offsets, all 16-B aligned)
     int32_t cars_per_block, waves_per_block, eighth, win_floats;   // win_floats: floats per LDS scan row: (eighth % 4) + (n_rays - 2*eighth) + 1, padded to 4

@@ -143,6 +143,8 @@ __device__ __forceinline__ int rank_below(uint64_t mask) { return __builtin_amdg
 // division.  The range test is done on the bit patterns of both operands at once: b - (lo + 1) is below hi - lo - 1 (unsigned)
 // exactly for lo < b < hi, and the OR of two such differences can only be below that if both are -- an OR that is not sends
 // the wave through the per-lane test and the division, which is then simply not needed.
+// CLAMP: +inf (a zero, or so small that its reciprocal overflows) comes back as FTGP_IV_MAX, as the ray specification wants it.
+template <bool CLAMP = false>
 __device__ __forceinline__ void rcp_abs2(float x, float y, float& rx, float& ry)
 {
     const float ax = fabsf(x), ay = fabsf(y);
@@ -152,7 +154,8 @@ __device__ __forceinline__ void rcp_abs2(float x, float y, float& rx, float& ry)
     const uint32_t lo1 = 0x0D800001u, span = 0x71800000u - 0x0D800001u;             // bit patterns of 2^-100 (+ 1) and 2^100
     if (__any(((__float_as_uint(ax) - lo1) | (__float_as_uint(ay) - lo1)) >= span)) {
         const bool oddx = !(ax > 0x1p-100f && ax < 0x1p100f), oddy = !(ay > 0x1p-100f && ay < 0x1p100f);      // also true for a NaN
-        const float zx = fabsf(1.0f / x), zy = fabsf(1.0f / y);
+        float zx = fabsf(1.0f / x), zy = fabsf(1.0f / y);
+        if (CLAMP) { zx = zx < FTGP_IV_MAX ? zx : FTGP_IV_MAX; zy = zy < FTGP_IV_MAX ? zy : FTGP_IV_MAX; }
         p = oddx ? zx : p; q = oddy ? zy : q;
     }
     rx = p; ry = q;
@@ -230,42 +233,41 @@ __device__ __forceinline__ void sweep_priority(bool second_half)
 // instruction (profiles/round4/salu_cost.log) -- and the compiler's loop spends 13 scalar-side instructions per iteration on mask
 // bookkeeping.  Here a lane leaves the loop by dropping out of exec (v_cmpx on "the cell's entry is a box", i.e. kx != 0), so the
 // body needs no live mask, finished rays hold their cell and crossing time for free (and burn no vector lanes), and the loop
-// closes with one branch on exec: 20 vector + 3 scalar-side instructions per iteration, + the near-boundary path.
-// In: exec = the lanes that hold a ray; ix, iy = (mirrored) cell, s = crossing time into it (0 at the origin).
+// closes with one branch on exec: 18 vector + 3 scalar-side instructions per iteration, + the near-boundary path.
+// In: exec = the lanes that hold a ray; mx, my = cells travelled (0 at the origin), s = crossing time into the cell (0 at the origin).
 // Out: w = entry of the terminal cell (0 = wall, FTGP_FIELD_OUT = ring), s = crossing time into it, exec as on entry.
-// The arithmetic is ftgp_ray_step / ftgp_ray_fix / ftgp_ray_commit of ftgp_march.h, instruction for instruction.
-// off0: the byte offset of the start cell's entry (ftgp_ray_offset_first: the first look-up may be served by a plane of its own, a finer
-// sector than the rest of the march uses).
-__device__ __forceinline__ void march_all(int& ix, int& iy, float& s, uint32_t& w, float pum, float pvm, float ivx, float ivy, float dum, float dvm,
-                                          int off0, int offC, int ax, int ay, float thr /* 0.5f - eps */, const void* field)
+// The arithmetic is ftgp_ray_step / ftgp_ray_fix / ftgp_ray_commit of ftgp_march.h, instruction for instruction: a crossing time is
+// fma((float)boundary, iv, -c) -- boundaries counted from the ray's own start cell (round 5; rounds 1-4: convert, subtract the origin's
+// absolute coordinate, multiply).  du, dv come in signed (the body reads their magnitudes through the operand modifier).
+// off0: the byte offset of the start cell's entry (= base).
+__device__ __forceinline__ void march_all(int& mx, int& my, float& s, uint32_t& w, float gu, float gv, float cx, float cy, float ivx, float ivy, float du, float dv,
+                                          int base, int ax, int ay, float thr /* 0.5f - eps */, const void* field)
 {
-    int a = off0, b, c, d, e, f, h, i;
+    int a, b, c, d, e, f, h, i;
     uint64_t stepx, sv, sq, ex0;
     asm volatile(
         "s_mov_b64 %[ex0], exec\n\t"
-        // the look-up of the cell a ray stands on: entry offset = ftgp_ray_offset(), far corner of its box, "is it a box at all"
-#define FTGP_MARCH_LOAD \
-        "global_load_ushort %[w], %[a], %[field]\n\t" \
+        // the look-up of the cell a ray stands on: far corner of its box, "is it a box at all"
+#define FTGP_MARCH_LOAD(addr) \
+        "global_load_ushort %[w], " addr ", %[field]\n\t" \
         "s_waitcnt vmcnt(0)\n\t" \
-        "v_add_u32_sdwa %[c], %[ix], %[w] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"     /* xe = ix + kx */ \
-        "v_add_u32_sdwa %[d], %[iy], %[w] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t"     /* ye = iy + ky */ \
-        "v_cmpx_ne_u32_e32 vcc, %[c], %[ix]\n\t"                         /* kx == 0: wall or ring cell -- the lane is done */
+        "v_add_u32_sdwa %[c], %[mx], %[w] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"     /* xe = mx + kx */ \
+        "v_add_u32_sdwa %[d], %[my], %[w] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t"     /* ye = my + ky */ \
+        "v_cmpx_ne_u32_e32 vcc, %[c], %[mx]\n\t"                         /* kx == 0: wall or ring cell -- the lane is done */
 #define FTGP_MARCH_LOOKUP \
-        "v_mad_i32_i24 %[a], %[iy], %[ay], %[offC]\n\t" \
-        "v_mad_i32_i24 %[a], %[ix], %[ax], %[a]\n\t" \
-        FTGP_MARCH_LOAD
-        FTGP_MARCH_LOAD                                                   // the start cell: its offset comes in with `a`
+        "v_mad_i32_i24 %[a], %[my], %[ay], %[base]\n\t"                  /* entry offset = ftgp_ray_offset() */ \
+        "v_mad_i32_i24 %[a], %[mx], %[ax], %[a]\n\t" \
+        FTGP_MARCH_LOAD("%[a]")
+        FTGP_MARCH_LOAD("%[base]")                                        // the start cell
         "s_cbranch_execz L_march_done_%=\n"
         "L_march_loop_%=:\n\t"
         "v_cvt_f32_i32_e32 %[a], %[c]\n\t"
         "v_cvt_f32_i32_e32 %[b], %[d]\n\t"
-        "v_sub_f32_e32 %[a], %[a], %[pum]\n\t"
-        "v_sub_f32_e32 %[b], %[b], %[pvm]\n\t"
-        "v_mul_f32_e32 %[a], %[ivx], %[a]\n\t"                           // sX = ((float)xe - pum) * ivx
-        "v_mul_f32_e32 %[b], %[ivy], %[b]\n\t"                           // sY = ((float)ye - pvm) * ivy
+        "v_fma_f32 %[a], %[a], %[ivx], -%[cx]\n\t"                       // sX = fma((float)xe, ivx, -cx): the box's far edge is the xe-th boundary
+        "v_fma_f32 %[b], %[b], %[ivy], -%[cy]\n\t"                       // sY
         "v_cmp_lt_f32_e64 %[stepx], %[a], %[b]\n\t"                      // the x edge of the box is reached first (a tie steps in y)
-        "v_fma_f32 %[e], %[dvm], %[a], %[pvm]\n\t"                       // landing estimate after an x-jump ...
-        "v_fma_f32 %[f], %[dum], %[b], %[pum]\n\t"                       // ... after a y-jump
+        "v_fma_f32 %[e], |%[dv]|, %[a], %[gv]\n\t"                       // landing estimate after an x-jump ...
+        "v_fma_f32 %[f], |%[du]|, %[b], %[gu]\n\t"                       // ... after a y-jump
         "v_cndmask_b32_e64 %[s], %[b], %[a], %[stepx]\n\t"               // s = sn (a lane that ended on this lookup left exec above and keeps its s)
         "v_cndmask_b32_e64 %[e], %[f], %[e], %[stepx]\n\t"               // v
         "v_cvt_flr_i32_f32_e32 %[h], %[e]\n\t"                           // t = floor(v)
@@ -274,21 +276,20 @@ __device__ __forceinline__ void march_all(int& ix, int& iy, float& s, uint32_t& 
         "v_cmp_gt_f32_e64 vcc, |%[f]|, %[thr]\n\t"                       // within eps of a pixel boundary: the specification's comparisons decide
         "s_cbranch_vccnz L_march_fix_%=\n"
         "L_march_commit_%=:\n\t"
-        "v_cndmask_b32_e64 %[ix], %[h], %[c], %[stepx]\n\t"
-        "v_cndmask_b32_e64 %[iy], %[d], %[h], %[stepx]\n\t"
+        "v_cndmask_b32_e64 %[mx], %[h], %[c], %[stepx]\n\t"
+        "v_cndmask_b32_e64 %[my], %[d], %[h], %[stepx]\n\t"
         FTGP_MARCH_LOOKUP                                                 // (the loop is rotated: its one taken branch is the one that closes it)
         "s_cbranch_execnz L_march_loop_%=\n\t"
         "s_branch L_march_done_%=\n"
         "L_march_fix_%=:\n\t"                                            // ftgp_ray_fix() for the lanes in vcc
         "s_and_saveexec_b64 %[sv], vcc\n\t"
-        "v_cndmask_b32_e64 %[a], %[pum], %[pvm], %[stepx]\n\t"           // transverse origin ...
+        "v_cndmask_b32_e64 %[a], %[cx], %[cy], %[stepx]\n\t"             // transverse c ...
         "v_cndmask_b32_e64 %[b], %[ivx], %[ivy], %[stepx]\n\t"           // ... reciprocal ...
-        "v_cndmask_b32_e64 %[f], %[ix], %[iy], %[stepx]\n\t"             // ... current cell ...
+        "v_cndmask_b32_e64 %[f], %[mx], %[my], %[stepx]\n\t"             // ... current cell ...
         "v_cndmask_b32_e64 %[i], %[c], %[d], %[stepx]\n\t"
         "v_add_u32_e32 %[i], -1, %[i]\n\t"                               // ... last cell of the box's span
         "v_rndne_f32_e32 %[e], %[e]\n\t"                                 // the boundary in doubt
-        "v_sub_f32_e32 %[a], %[e], %[a]\n\t"
-        "v_mul_f32_e32 %[a], %[b], %[a]\n\t"                             // its crossing time, the specification's way
+        "v_fma_f32 %[a], %[e], %[b], -%[a]\n\t"                          // its crossing time, the specification's way
         "v_cvt_i32_f32_e32 %[b], %[e]\n\t"
         "v_cmp_lt_f32_e64 vcc, %[a], %[s]\n\t"
         "v_cmp_le_f32_e64 %[sq], %[a], %[s]\n\t"
@@ -301,11 +302,11 @@ __device__ __forceinline__ void march_all(int& ix, int& iy, float& s, uint32_t& 
         "s_branch L_march_commit_%=\n"
         "L_march_done_%=:\n\t"
         "s_mov_b64 exec, %[ex0]"
-        : [ix] "+v"(ix), [iy] "+v"(iy), [s] "+v"(s), [w] "+v"(w),
-          [a] "+v"(a), [b] "=&v"(b), [c] "=&v"(c), [d] "=&v"(d), [e] "=&v"(e), [f] "=&v"(f), [h] "=&v"(h), [i] "=&v"(i),
+        : [mx] "+v"(mx), [my] "+v"(my), [s] "+v"(s), [w] "+v"(w),
+          [a] "=&v"(a), [b] "=&v"(b), [c] "=&v"(c), [d] "=&v"(d), [e] "=&v"(e), [f] "=&v"(f), [h] "=&v"(h), [i] "=&v"(i),
           [stepx] "=&s"(stepx), [sv] "=&s"(sv), [sq] "=&s"(sq), [ex0] "=&s"(ex0)
-        : [pum] "v"(pum), [pvm] "v"(pvm), [ivx] "v"(ivx), [ivy] "v"(ivy), [dum] "v"(dum), [dvm] "v"(dvm),
-          [offC] "v"(offC), [ax] "v"(ax), [ay] "v"(ay), [thr] "s"(thr), [field] "s"(field)
+        : [gu] "v"(gu), [gv] "v"(gv), [cx] "v"(cx), [cy] "v"(cy), [ivx] "v"(ivx), [ivy] "v"(ivy), [du] "v"(du), [dv] "v"(dv),
+          [base] "v"(base), [ax] "v"(ax), [ay] "v"(ay), [thr] "s"(thr), [field] "s"(field)
         : "vcc", "scc", "memory");
 }
 
@@ -362,7 +363,7 @@ __device__ __forceinline__ void lidar_groups(const DeviceParams& P, ScalarParams
             if (!active) return;
             uint32_t w = FTGP_FIELD_OUT;
             STAMP(tb);
-            march_all(ray.ix, ray.iy, ray.s, w, ray.pum, ray.pvm, ray.ivx, ray.ivy, ray.dum, ray.dvm, ftgp_ray_offset_first(ray), ray.offC, ray.ax, ray.ay, thr, field);
+            march_all(ray.mx, ray.my, ray.s, w, ray.gu, ray.gv, ray.cx, ray.cy, ray.ivx, ray.ivy, du, dv, ray.base, ray.ax, ray.ay, thr, field);
             STAMP(tc); STAMP_ADD(10, tc - tb); STAMP_ADD(9, 1);
             float r = (w == 0u) ? fabsf(ray.s) : ray.result;
             if (MULTI && FTGP_DIAG_RUN_MATES) {
@@ -405,7 +406,7 @@ __device__ __forceinline__ void lidar_groups(const DeviceParams& P, ScalarParams
             const float pu = fmaf(du, -r0, f4.x);
             const float pv = fmaf(dv, -r0, f4.y);
             float ivx, ivy;
-            rcp_abs2(du, dv, ivx, ivy);
+            rcp_abs2<true>(du, dv, ivx, ivy);
             ray.result = -1.0f;
             sector = ftgp_ray_sector(du, dv, ivx, ivy, nsf);
             ftgp_ray_place(ray, pu, pv, du, dv, ivx, ivy, sector, W, H, fstride, plane256, true, &P.sector_tab[0][0]);

@@ -26,6 +26,7 @@
  *     and, in the nidc/fast policies only, atan/ceil.
  *   - LiDAR march: IEEE binary32 with explicit fmaf where written.
  */
+#include <float.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -345,28 +346,47 @@ static float ray_vs_cars(const OracleEnv *e, int car_index, double lcx, double l
 }
 
 /*
- * THE SPECIFICATION of a ray (binary32): plain cell-by-cell DDA.  The ray p(s) = (pu + du*s, pv + dv*s) crosses the
- * integer pixel boundary b of an axis at  sX(b) = ((float)b - pu) * (1/du)  resp.  sY(b) = ((float)b - pv) * (1/dv);
- * from a cell the next step is the x-neighbour iff sX(next x boundary) < sY(next y boundary) (a tie steps in y);
- * the range is the crossing time of the step that enters the first wall cell (0 if the start cell is a wall,
- * -1 if the ray leaves the image).  Every quantity is a function of (cell, ray) alone -- nothing accumulates --
- * so any implementation that skips wall-free cells and re-synchronises with these comparisons gives the same bits.
+ * THE SPECIFICATION of a ray (binary32): plain cell-by-cell DDA with crossing times in coordinates relative to the start cell.
+ * Start cell (ix0, iy0) = floor of the origin.  Per axis (p = origin coordinate, i0 = its floor, d = direction component):
+ *   f = p - (float)i0 (exact);  g = d < 0 ? 1.0f - f : f  (the offset inside the start cell, seen in the direction of travel);
+ *   iv = |1 / d| (IEEE division), +inf replaced by FLT_MAX (d = 0: the axis is never stepped, and 0 * iv stays 0);  c = g * iv;
+ *   S(k) = fma((float)k, iv, -c) = crossing time of the k-th cell boundary the ray meets on this axis, k = 1, 2, ...
+ * After mx steps in x and my steps in y the next step is the x-neighbour iff Sx(mx + 1) < Sy(my + 1) (a tie steps in y); the range is
+ * the crossing time of the step that enters the first wall cell (0 if the start cell is a wall, -1 if the ray leaves the image).
+ * Every quantity is a function of (cell, ray) alone -- nothing accumulates -- so any implementation that skips wall-free cells and
+ * re-synchronises with these comparisons gives the same bits.  (Rounds 1-4: S = ((float)b - p) * (1 / d) on absolute boundary
+ * coordinates b; DESIGN.md section 4 says why it changed.)
  */
+typedef struct { float ivx, ivy, cx, cy; int sx, sy; } RaySpec;      /* sx, sy = +1 / -1: direction of travel in the image */
+
+static float spec_iv(float d) { float z = fabsf(1.0f / d); return z < FLT_MAX ? z : FLT_MAX; }
+
+static void ray_spec(RaySpec *q, float pu, float pv, float du, float dv, int ix0, int iy0)
+{
+    const float fu = pu - (float)ix0, fv = pv - (float)iy0;
+    const float gu = (du < 0.0f) ? 1.0f - fu : fu, gv = (dv < 0.0f) ? 1.0f - fv : fv;
+    q->ivx = spec_iv(du); q->ivy = spec_iv(dv);
+    q->cx = gu * q->ivx; q->cy = gv * q->ivy;
+    q->sx = (du < 0.0f) ? -1 : 1; q->sy = (dv < 0.0f) ? -1 : 1;
+}
+#define SPEC_SX(q, k) fmaf((float)(k), (q).ivx, -(q).cx)
+#define SPEC_SY(q, k) fmaf((float)(k), (q).ivy, -(q).cy)
+
 static float march_plain_f32(const OracleEnv *e, float pu, float pv, float du, float dv)
 {
     const int W = e->cfg.track.width, H = e->cfg.track.height;
-    int ix = (int)floorf(pu), iy = (int)floorf(pv);
-    if (ix < 0 || ix >= W || iy < 0 || iy >= H) return -1.0f;
-    const float inv_du = (du != 0.0f) ? 1.0f / du : 0.0f;
-    const float inv_dv = (dv != 0.0f) ? 1.0f / dv : 0.0f;
+    const int ix0 = (int)floorf(pu), iy0 = (int)floorf(pv);
+    if (!(pu == pu) || !(pv == pv) || ix0 < 0 || ix0 >= W || iy0 < 0 || iy0 >= H) return -1.0f;
+    RaySpec q; ray_spec(&q, pu, pv, du, dv, ix0, iy0);
+    int mx = 0, my = 0;
     float s = 0.0f;
     for (;;) {
-        if (wall_at(e, ix, iy)) return fabsf(s);   /* |s|: a ray that starts on a boundary can produce -0 */
-        float sX = (du != 0.0f) ? ((float)((du > 0.0f) ? ix + 1 : ix) - pu) * inv_du : INFINITY;
-        float sY = (dv != 0.0f) ? ((float)((dv > 0.0f) ? iy + 1 : iy) - pv) * inv_dv : INFINITY;
-        if (sX < sY) { s = sX; ix += (du > 0.0f) ? 1 : -1; }
-        else         { s = sY; iy += (dv > 0.0f) ? 1 : -1; }
+        const int ix = ix0 + q.sx * mx, iy = iy0 + q.sy * my;
         if (ix < 0 || ix >= W || iy < 0 || iy >= H) return -1.0f;
+        if (wall_at(e, ix, iy)) return fabsf(s);   /* |s|: a ray that starts on a boundary can produce -0 */
+        const float sX = SPEC_SX(q, mx + 1), sY = SPEC_SY(q, my + 1);
+        if (sX < sY) { s = sX; mx += 1; }
+        else         { s = sY; my += 1; }
     }
 }
 
@@ -378,54 +398,42 @@ static float march_plain_f32(const OracleEnv *e, float pu, float pv, float du, f
 static float march_f32(const OracleEnv *e, float pu, float pv, float du, float dv)
 {
     const int W = e->cfg.track.width, H = e->cfg.track.height;
-    int ix = (int)floorf(pu), iy = (int)floorf(pv);
-    if (ix < 0 || ix >= W || iy < 0 || iy >= H) return -1.0f;
-    const int xnz = du != 0.0f, ynz = dv != 0.0f, xpos = du > 0.0f, ypos = dv > 0.0f;
-    const float inv_du = xnz ? 1.0f / du : 0.0f;
-    const float inv_dv = ynz ? 1.0f / dv : 0.0f;
-#define SXF(b) (((float)(b) - pu) * inv_du)
-#define SYF(b) (((float)(b) - pv) * inv_dv)
+    const int ix0 = (int)floorf(pu), iy0 = (int)floorf(pv);
+    if (!(pu == pu) || !(pv == pv) || ix0 < 0 || ix0 >= W || iy0 < 0 || iy0 >= H) return -1.0f;
+    RaySpec q; ray_spec(&q, pu, pv, du, dv, ix0, iy0);
+    const float adu = fabsf(du), adv = fabsf(dv);
+    const float fu = pu - (float)ix0, fv = pv - (float)iy0;
+    const float gu = (du < 0.0f) ? 1.0f - fu : fu, gv = (dv < 0.0f) ? 1.0f - fv : fv;
+    int mx = 0, my = 0;          /* cells travelled along each axis */
     float s = 0.0f;
     for (int it = 0; it < 1 << 20; ++it) {
-        int k = e->field[(size_t)iy * W + ix];
+        const int ix = ix0 + q.sx * mx, iy = iy0 + q.sy * my;
+        if (ix < 0 || ix >= W || iy < 0 || iy >= H) return -1.0f;
+        const int k = e->field[(size_t)iy * W + ix];            /* the (2k-1)^2 block around the cell is wall-free */
         if (k == 0) return fabsf(s);
-        int bxi = xpos ? ix + k : ix - k + 1;
-        int byi = ypos ? iy + k : iy - k + 1;
-        float sX = xnz ? SXF(bxi) : INFINITY;
-        float sY = ynz ? SYF(byi) : INFINITY;
+        const float sX = SPEC_SX(q, mx + k), sY = SPEC_SY(q, my + k);      /* leaving the block: k boundaries further on */
         if (sX < sY) {
             s = sX;
-            int t = iy;
-            if (ynz) {   /* y boundaries already crossed at time s: those with sY(b) <= s */
-                t = (int)floorf(fmaf(dv, s, pv));
-                if (ypos) {
-                    int hi = iy + k - 1; if (t < iy) t = iy; if (t > hi) t = hi;
-                    if (t > iy && !(SYF(t) <= s)) t -= 1; else if (t < hi && (SYF(t + 1) <= s)) t += 1;
-                } else {
-                    int lo = iy - k + 1; if (t > iy) t = iy; if (t < lo) t = lo;
-                    if (t < iy && !(SYF(t + 1) <= s)) t += 1; else if (t > lo && (SYF(t) <= s)) t -= 1;
-                }
-            }
-            ix = xpos ? ix + k : ix - k; iy = t;
+            /* y boundaries already crossed at time s: those with Sy(b) <= s; estimate, then settle with the comparisons */
+            int t = (int)floorf(fmaf(adv, s, gv));
+            const int hi = my + k - 1;
+            if (t < my) t = my;
+            if (t > hi) t = hi;
+            while (t > my && !(SPEC_SY(q, t) <= s)) t -= 1;
+            while (t < hi && (SPEC_SY(q, t + 1) <= s)) t += 1;
+            mx += k; my = t;
         } else {
             s = sY;
-            int t = ix;
-            if (xnz) {   /* x boundaries already crossed at time s: those with sX(b) < s (a tie steps in y first) */
-                t = (int)floorf(fmaf(du, s, pu));
-                if (xpos) {
-                    int hi = ix + k - 1; if (t < ix) t = ix; if (t > hi) t = hi;
-                    if (t > ix && !(SXF(t) < s)) t -= 1; else if (t < hi && (SXF(t + 1) < s)) t += 1;
-                } else {
-                    int lo = ix - k + 1; if (t > ix) t = ix; if (t < lo) t = lo;
-                    if (t < ix && !(SXF(t + 1) < s)) t += 1; else if (t > lo && (SXF(t) < s)) t -= 1;
-                }
-            }
-            iy = ypos ? iy + k : iy - k; ix = t;
+            /* x boundaries already crossed at time s: those with Sx(b) < s (a tie steps in y first) */
+            int t = (int)floorf(fmaf(adu, s, gu));
+            const int hi = mx + k - 1;
+            if (t < mx) t = mx;
+            if (t > hi) t = hi;
+            while (t > mx && !(SPEC_SX(q, t) < s)) t -= 1;
+            while (t < hi && (SPEC_SX(q, t + 1) < s)) t += 1;
+            my += k; mx = t;
         }
-        if (ix < 0 || ix >= W || iy < 0 || iy >= H) return -1.0f;
     }
-#undef SXF
-#undef SYF
     return -1.0f;
 }
 

@@ -54,7 +54,7 @@ int main(int argc, char** argv)
         for (int j = 0; j < R; ++j) {
             const float dxw = fmaf(chf, bx[j], -(shf * by[j])), dyw = fmaf(shf, bx[j], chf * by[j]);
             const float du = dxw * isx, dv = -(dyw * isy);
-            FtgpRay r; ftgp_ray_init(r, fmaf(du, -r0, u0), fmaf(dv, -r0, v0), du, dv, fabsf(1.0f / du), fabsf(1.0f / dv), W, H, fstride, plane256);
+            FtgpRay r; ftgp_ray_init(r, fmaf(du, -r0, u0), fmaf(dv, -r0, v0), du, dv, ftgp_iv(du), ftgp_iv(dv), W, H, fstride, plane256);
             int mine = 0;
             for (int n = 0; n < 100000; ++n) {
                 const size_t idx = (uint32_t)ftgp_ray_offset(r) >> 1;

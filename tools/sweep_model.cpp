@@ -86,7 +86,7 @@ int main(int argc, char** argv)
             for (int j = 0; j < R; ++j) {
                 const float dxw = fmaf(chf, bx[j], -(shf * by[j])), dyw = fmaf(shf, bx[j], chf * by[j]);
                 const float du = dxw * isx, dv = -(dyw * isy);
-                FtgpRay r; ftgp_ray_init(r, fmaf(du, -r0, u0), fmaf(dv, -r0, v0), du, dv, fabsf(1.0f / du), fabsf(1.0f / dv), W, H, fstride, plane256);
+                FtgpRay r; ftgp_ray_init(r, fmaf(du, -r0, u0), fmaf(dv, -r0, v0), du, dv, ftgp_iv(du), ftgp_iv(dv), W, H, fstride, plane256);
                 int n = 0;
                 for (; n < 100000; ++n) {
                     const uint32_t wq = field[ftgp_ray_offset(r) >> 1];
@@ -143,7 +143,7 @@ int main(int argc, char** argv)
             for (int j = 0; j < R; ++j) {
                 const float dxw = fmaf(chf, bx[j], -(shf * by[j])), dyw = fmaf(shf, bx[j], chf * by[j]);
                 const float du = dxw * isx, dv = -(dyw * isy);
-                FtgpRay r; ftgp_ray_init(r, fmaf(du, -r0, u0), fmaf(dv, -r0, v0), du, dv, fabsf(1.0f / du), fabsf(1.0f / dv), W, H, fstride, plane256);
+                FtgpRay r; ftgp_ray_init(r, fmaf(du, -r0, u0), fmaf(dv, -r0, v0), du, dv, ftgp_iv(du), ftgp_iv(dv), W, H, fstride, plane256);
                 int n = 1;
                 for (; n < 100000; ++n) {
                     const uint32_t wq = field[ftgp_ray_offset(r) >> 1];
@@ -179,7 +179,7 @@ int main(int argc, char** argv)
                 for (int j = 0; j < R; ++j) {
                     const float dxw = fmaf(c2, bx[j], -(s2 * by[j])), dyw = fmaf(s2, bx[j], c2 * by[j]);
                     const float du = dxw * isx, dv = -(dyw * isy);
-                    FtgpRay r; ftgp_ray_init(r, fmaf(du, -r0, u2), fmaf(dv, -r0, v2), du, dv, fabsf(1.0f / du), fabsf(1.0f / dv), W, H, fstride, plane256);
+                    FtgpRay r; ftgp_ray_init(r, fmaf(du, -r0, u2), fmaf(dv, -r0, v2), du, dv, ftgp_iv(du), ftgp_iv(dv), W, H, fstride, plane256);
                     int n = 1;
                     for (; n < 100000; ++n) {
                         const uint32_t wq = field[ftgp_ray_offset(r) >> 1];
@@ -252,7 +252,7 @@ int main(int argc, char** argv)
                             const float chf = (float)ch, shf = (float)sh;
                             const float dxw = fmaf(chf, bx[j], -(shf * by[j])), dyw = fmaf(shf, bx[j], chf * by[j]);
                             const float du = dxw * isx, dv = -(dyw * isy);
-                            ftgp_ray_init(l.r, fmaf(du, -r0, u0), fmaf(dv, -r0, v0), du, dv, fabsf(1.0f / du), fabsf(1.0f / dv), W, H, fstride, plane256);
+                            ftgp_ray_init(l.r, fmaf(du, -r0, u0), fmaf(dv, -r0, v0), du, dv, ftgp_iv(du), ftgp_iv(dv), W, H, fstride, plane256);
                             l.done = false;
                             if (iso_mode) {          // what-if: a first jump without a lookup, by the clearance of the LiDAR centre (one value per car)
                                 // D = distance (pixels) from the centre to the nearest wall pixel or image edge, margin sqrt(2) + slack
@@ -269,8 +269,7 @@ int main(int argc, char** argv)
                                     const float lx = fmaf(du, t0, u0), ly = fmaf(dv, t0, v0);
                                     const float fx = lx - floorf(lx), fy = ly - floorf(ly);
                                     if (fabsf(fx - 0.5f) <= 0.5f - eps && fabsf(fy - 0.5f) <= 0.5f - eps) {
-                                        const int mxm = du < 0 ? -1 : 0, mym = dv < 0 ? -1 : 0;
-                                        l.r.ix = (int)floorf(lx) ^ mxm; l.r.iy = (int)floorf(ly) ^ mym; ++iso_used;
+                                        l.r.mx = abs((int)floorf(lx) - (int)floorf(fmaf(du, -r0, u0))); l.r.my = abs((int)floorf(ly) - (int)floorf(fmaf(dv, -r0, v0))); ++iso_used;
                                     } else ++iso_near;
                                 }
                             }
