@@ -9,7 +9,7 @@ envs, rays, policy, steps = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int
 cars = int(sys.argv[5]) if len(sys.argv) > 5 else 1
 track = sys.argv[6] if len(sys.argv) > 6 else "track"
 lib = capi.CLib(os.environ["FTGP_LIB"], "ftgp_") if os.environ.get("FTGP_LIB") else capi.load()
-with capi.Env(lib, load_track(track), n_envs=envs, cars_per_env=cars, n_rays=rays, spawn_mode=1, seed=1234, lidar_mode=os.environ.get("FTGP_PROF_LIDAR", "rangefinder")) as e:      # the spawn rule bench.py uses
+with capi.Env(lib, load_track(track), n_envs=envs, cars_per_env=cars, n_rays=rays, spawn_mode=int(os.environ.get('PROF_SPAWN_MODE', '1')), seed=1234, lidar_mode=os.environ.get("FTGP_PROF_LIDAR", "rangefinder")) as e:      # the spawn rule bench.py uses
     e.rollout(policy, 50); e.last_kernel_ms()
     e.rollout(policy, steps)
     print("kernel ms", e.last_kernel_ms(), flush=True)

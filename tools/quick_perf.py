@@ -14,7 +14,7 @@ for path in libs:
     lib = capi.CLib(path, "ftgp_")
     out = []
     for name, policy, envs, cars, steps in cases:
-        with capi.Env(lib, load_track(name), n_envs=envs, cars_per_env=cars, n_rays=1080, spawn_mode=1 if (cars == 1 or os.environ.get('QUICK_SPAWN')) else 0, seed=1234) as e:      # QUICK_SPAWN=1: bench.py's spawn rule for multi-car envs too
+        with capi.Env(lib, load_track(name), n_envs=envs, cars_per_env=cars, n_rays=1080, spawn_mode=int(os.environ.get('QUICK_SPAWN_MODE', 1 if (cars == 1 or os.environ.get('QUICK_SPAWN')) else 0)), seed=1234) as e:      # QUICK_SPAWN=1: bench.py's spawn rule for multi-car envs too
             if policy == "roster":
                 e.set_car_policies(["nidc", "fast", "nidc"]); policy = "per_car"
             e.rollout(policy, 100); e.last_kernel_ms(); best = 1e9
