@@ -90,6 +90,10 @@ struct FtgpEnv {
     double* h_metrics = nullptr;      // pinned [2][FTGP_METRIC_DOUBLES]: THIS rank's records only (the gathered ones land in h_gather)
     double* h_metrics_dev = nullptr;  // the same buffer as the device sees it: the step kernel's epilogue writes straight into it
     double* h_gather = nullptr;       // pinned [world][FTGP_METRIC_DOUBLES]: landing buffer of the all-gather
+    double* h_wg_metrics = nullptr;   // pinned [2][workgroups][FTGP_METRIC_DOUBLES]: the workgroups' partial records of a launch (one rank, no communicator:
+                                      // nothing on the device needs the launch's record, the host adds the partial records up -- collect_slot())
+    int n_blocks = 0;                 // workgroups of a step launch
+    bool slot_partial[2] = { false, false };   // the record of that slot's launch is in h_wg_metrics (partial records), not in h_metrics
     bool gather_open = false;         // ftgp_metrics_allgather_begin without its _end
     int gather_slot = 0;              // the slot that exchange reads
     hipEvent_t gather_event = nullptr;   // what its _end waits for: ev_gather (side stream / metrics kernel) or the slot's own ev_stop
@@ -233,6 +237,21 @@ bool uses_disparity_driver(const FtgpEnv* e, int policy)
     return false;
 }
 
+// This rank's record of the launch (or metrics kernel) that wrote `slot`, once its event has been waited for: the record itself, or the
+// sum of the workgroups' partial records (sums of integers, a minimum and a maximum: exact in any order -- bit-identical to what the
+// step kernel's last workgroup or ftgp_metrics_kernel compute on the device).
+void collect_slot(const FtgpEnv* e, int slot, double* out)
+{
+    if (!e->slot_partial[slot]) { memcpy(out, e->h_metrics + (size_t)slot * FTGP_METRIC_DOUBLES, sizeof(double) * FTGP_METRIC_DOUBLES); return; }
+    double v[FTGP_METRIC_DOUBLES] = { 0, 0, 0, 0, 0, 0, INFINITY, -INFINITY };
+    const double* r = e->h_wg_metrics + (size_t)slot * e->n_blocks * FTGP_METRIC_DOUBLES;
+    for (int b = 0; b < e->n_blocks; ++b, r += FTGP_METRIC_DOUBLES) {
+        for (int q = 0; q < 6; ++q) v[q] += r[q];
+        v[6] = fmin(v[6], r[6]); v[7] = fmax(v[7], r[7]);
+    }
+    memcpy(out, v, sizeof v);
+}
+
 int launch_steps(FtgpEnv* e, int policy, int n_steps)
 {
     e->rows_valid = false;
@@ -252,7 +271,7 @@ int launch_steps(FtgpEnv* e, int policy, int n_steps)
         if (e->comm) HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_gather, 0));
         else if (!e->gather_held) {
             HIP_TRY(wait_event(e, e->gather_event));
-            memcpy(e->held, e->h_metrics + (size_t)slot * FTGP_METRIC_DOUBLES, sizeof e->held);
+            collect_slot(e, slot, e->held);
             e->gather_held = true;
         }
     }
@@ -267,7 +286,11 @@ int launch_steps(FtgpEnv* e, int policy, int n_steps)
         hipEvent_t ev0 = ext ? e->ev_start : nullptr, ev1 = ext ? e->ev_stop[slot] : nullptr;
         const bool roster = policy == FTGP_POLICY_PER_CAR;
         e->last_roster = roster;
-#define FTGP_LAUNCH(M, F, R) hipExtLaunchKernelGGL((ftgp_step_kernel<M, F, R>), grid, block, lds, e->stream, ev0, ev1, 0, e->d_params, policy, n_steps, slot)
+        // one rank and no communicator: the workgroups' partial records go straight to pinned host memory (bit 1 of the slot argument)
+        const bool partial = e->h_wg_metrics != nullptr && e->comm == nullptr && e->d_wg_metrics != nullptr;
+        const int slot_arg = slot | (partial ? 2 : 0);
+        e->slot_partial[slot] = partial;
+#define FTGP_LAUNCH(M, F, R) hipExtLaunchKernelGGL((ftgp_step_kernel<M, F, R>), grid, block, lds, e->stream, ev0, ev1, 0, e->d_params, policy, n_steps, slot_arg)
         if (e->multi) { if (fake) FTGP_LAUNCH(true, true, true); else if (roster) FTGP_LAUNCH(true, false, true); else FTGP_LAUNCH(true, false, false); }
         else          { if (fake) FTGP_LAUNCH(false, true, true); else if (roster) FTGP_LAUNCH(false, false, true); else FTGP_LAUNCH(false, false, false); }
 #undef FTGP_LAUNCH
@@ -382,6 +405,7 @@ int ftgp_destroy(FtgpEnv* e)
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (e->h_metrics) (void)hipHostFree(e->h_metrics);
     if (e->h_gather) (void)hipHostFree(e->h_gather);
+    if (e->h_wg_metrics) (void)hipHostFree(e->h_wg_metrics);
     if (e->ev_gather) (void)hipEventDestroy(e->ev_gather);
     if (e->ev_start) (void)hipEventDestroy(e->ev_start);
     for (hipEvent_t ev : e->ev_stop) if (ev) (void)hipEventDestroy(ev);
@@ -441,6 +465,9 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
         }                                                                                          \
     } while (0)
     CREATE_TRY(hipSetDevice(e->device));
+    // FTGP_WAIT_SPIN=1: the host waits for a launch by spinning instead of blocking on the interrupt (hipDeviceScheduleSpin: a CPU core per
+    // waiting handle for a shorter wake-up; measured: tools/launch_host.sh).  Best effort: a device that is already active keeps its flags.
+    if (const char* sv = getenv("FTGP_WAIT_SPIN")) { if (atoi(sv) == 1) (void)hipSetDeviceFlags(hipDeviceScheduleSpin); (void)hipGetLastError(); }
     CREATE_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     CREATE_TRY(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
     CREATE_TRY(hipEventCreate(&e->ev_start));
@@ -685,6 +712,11 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
         CREATE_TRY(hipMalloc(&e->d_wg_ticket, sizeof(unsigned int)));
         CREATE_TRY(hipMemsetAsync(e->d_wg_ticket, 0, sizeof(unsigned int), e->stream));
         P.wg_metrics = e->d_wg_metrics; P.wg_ticket = e->d_wg_ticket; P.metrics_dev = e->d_metrics; P.metrics_host = e->h_metrics_dev;
+        e->n_blocks = (int)blocks;
+        if (!getenv("FTGP_NO_HOST_SUM")) {           // (diagnostic switch: the device-side hand-off of the record also with one rank)
+            CREATE_TRY(hipHostMalloc(&e->h_wg_metrics, sizeof(double) * FTGP_METRIC_DOUBLES * 2 * blocks, hipHostMallocMapped));
+            CREATE_TRY(hipHostGetDevicePointer((void**)&P.wg_metrics_host, e->h_wg_metrics, 0));
+        }
     }
     CREATE_TRY(hipMalloc(&e->d_prog, sizeof(int32_t) * FTGP_PROGRESS_INTS * n_cars));
     CREATE_TRY(hipMalloc(&e->d_core, sizeof(double) * kCoreDoubles * n_cars));
@@ -945,13 +977,20 @@ int ftgp_get_steps(FtgpEnv* e, int64_t* out)
 // the record of this GPU: the step kernel's last workgroup has written it into pinned memory (slot cur_slot), or ftgp_metrics_kernel does now
 static int metrics_to_host(FtgpEnv* e, double* out)
 {
-    double* slot_host = e->h_metrics + (size_t)e->cur_slot * FTGP_METRIC_DOUBLES;
     if (!e->launch_metrics_valid) {
+        // An exchange that was begun on this very slot and not ended yet (one rank: its "exchange" IS the slot in pinned memory) promised the
+        // record of the state at its begin: put that aside before the slot is refreshed with the present state's.
+        if (e->gather_open && e->gather_slot == e->cur_slot && !e->comm && !e->gather_held) {
+            HIP_TRY(wait_event(e, e->gather_event));
+            collect_slot(e, e->cur_slot, e->held);
+            e->gather_held = true;
+        }
         hipLaunchKernelGGL(ftgp_metrics_kernel, dim3(1), dim3(FTGP_METRIC_THREADS), 0, e->stream, e->P, e->h_metrics_dev + (size_t)e->cur_slot * FTGP_METRIC_DOUBLES);
         HIP_TRY(hipGetLastError());
+        e->slot_partial[e->cur_slot] = false;
     }
     HIP_TRY(hipStreamSynchronize(e->stream));
-    memcpy(out, slot_host, sizeof(double) * FTGP_METRIC_DOUBLES);
+    collect_slot(e, e->cur_slot, out);
     return 0;
 }
 
@@ -980,12 +1019,24 @@ int ftgp_comm_init(FtgpEnv* e, const uint8_t id[128], int rank, int world_size)
     if (int rc = load_rccl()) return rc;
     HIP_TRY(hipSetDevice(e->device));
     Id128 uid; memcpy(uid.internal, id, 128);
-    int r = g_rccl.CommInitRank(&e->comm, world_size, uid, rank);
-    if (r != 0) { e->comm = nullptr; return fail(FTGP_ERR_COMM, "ncclCommInitRank: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"); }
+    // the gathered records get buffers of their own (this rank's record slots, h_metrics, written by the step kernel, stay untouched) -- allocated
+    // BEFORE the communicator: a handle never holds a communicator without them
+    double* d_gather = nullptr; double* h_gather = nullptr;
+    if (hipMalloc(&d_gather, sizeof(double) * FTGP_METRIC_DOUBLES * (size_t)world_size) != hipSuccess ||
+        hipHostMalloc(&h_gather, sizeof(double) * FTGP_METRIC_DOUBLES * (size_t)world_size, hipHostMallocDefault) != hipSuccess) {
+        if (d_gather) (void)hipFree(d_gather);
+        return fail(FTGP_ERR_HIP, "ftgp_comm_init: no memory for the gathered records%s");
+    }
+    void* comm = nullptr;
+    int r = g_rccl.CommInitRank(&comm, world_size, uid, rank);
+    if (r != 0) {
+        (void)hipFree(d_gather); (void)hipHostFree(h_gather);
+        return fail(FTGP_ERR_COMM, "ncclCommInitRank: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    }
+    // launches from here on leave their record on the device (no partial records to the host); one that is still in flight finishes first
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->comm = comm; e->d_gather = d_gather; e->h_gather = h_gather;
     e->rank = rank; e->world = world_size;
-    // the gathered records get buffers of their own: this rank's record slots (h_metrics, written by the step kernel) stay untouched
-    HIP_TRY(hipMalloc(&e->d_gather, sizeof(double) * FTGP_METRIC_DOUBLES * (size_t)world_size));
-    HIP_TRY(hipHostMalloc(&e->h_gather, sizeof(double) * FTGP_METRIC_DOUBLES * (size_t)world_size, hipHostMallocDefault));
     return 0;
 }
 
@@ -997,13 +1048,16 @@ int ftgp_metrics_allgather_begin(FtgpEnv* e)
     const int slot = e->cur_slot;
     const size_t so = (size_t)slot * FTGP_METRIC_DOUBLES;
     const bool rccl = e->comm != nullptr;            // a one-rank communicator goes through RCCL too (that is how one GPU tests the path)
-    if (!e->launch_metrics_valid) {      // otherwise the slot already holds this state's record (step kernel epilogue), on the device and in pinned memory
+    // a communicator that arrived after a launch whose record went to the host as partial records: the device has no copy of that record
+    const bool refresh = !e->launch_metrics_valid || (rccl && e->slot_partial[slot]);
+    if (refresh) {                       // otherwise the slot already holds this state's record (step kernel epilogue), on the device and in pinned memory
         hipLaunchKernelGGL(ftgp_metrics_kernel, dim3(1), dim3(FTGP_METRIC_THREADS), 0, e->stream, e->P, rccl ? e->d_metrics + so : e->h_metrics_dev + so);
         HIP_TRY(hipGetLastError());
+        e->slot_partial[slot] = false;
     }
     e->gather_held = false;
     if (!rccl) {                         // one rank: the "exchange" is the record's arrival in pinned memory
-        if (e->launch_metrics_valid && e->timed) e->gather_event = e->ev_stop[slot];      // ... with the launch that wrote it: nothing to enqueue
+        if (!refresh && e->timed) e->gather_event = e->ev_stop[slot];      // ... with the launch that wrote it: nothing to enqueue
         else { HIP_TRY(hipEventRecord(e->ev_gather, e->stream)); e->gather_event = e->ev_gather; }
     } else {
         // the record is produced on the compute stream; everything else happens on the side stream, beside the next launch
@@ -1028,7 +1082,7 @@ int ftgp_metrics_allgather_end(FtgpEnv* e, double* out)
     e->gather_open = false;
     if (e->comm) memcpy(out, e->h_gather, sizeof(double) * FTGP_METRIC_DOUBLES * (size_t)e->world);
     else if (e->gather_held) memcpy(out, e->held, sizeof e->held);
-    else memcpy(out, e->h_metrics + (size_t)e->gather_slot * FTGP_METRIC_DOUBLES, sizeof(double) * FTGP_METRIC_DOUBLES);
+    else collect_slot(e, e->gather_slot, out);
     return 0;
 }
 

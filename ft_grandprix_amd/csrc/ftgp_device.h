@@ -105,6 +105,8 @@ struct DeviceParams {
     unsigned int* wg_ticket;
     double* metrics_dev;          // [2][FTGP_METRIC_DOUBLES]: the launch's slot (a kernel argument, alternating per launch) says which
     double* metrics_host;         // [2][FTGP_METRIC_DOUBLES]
+    double* wg_metrics_host;      // [2][workgroups][FTGP_METRIC_DOUBLES] pinned host memory: the partial records of a launch whose record nothing on the device
+                                  // needs (one rank, no communicator) -- the host adds them up
     alignas(16) int32_t sector_tab[FTGP_SECTORS][4];     // ftgp_sector_entry() of every sector (staged into LDS with the head of the block)
     FtgpVehicle veh;              // host-side copy (the step kernel reads the LDS image VehLds; from here on nothing is staged into LDS)
     double wheel_load[4];

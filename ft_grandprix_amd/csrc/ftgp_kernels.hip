@@ -1231,12 +1231,18 @@ __device__ __forceinline__ double wave_total_f64(double x) { return wave_reduce_
 __device__ __forceinline__ double wave_least_f64(double x) { return wave_reduce_f64_dpp<true>(x, [](double a, double b) { return fmin(a, b); }); }
 __device__ __forceinline__ double wave_most_f64(double x) { return wave_reduce_f64_dpp<true>(x, [](double a, double b) { return fmax(a, b); }); }
 
+// One rank and no communicator (HOST_SUM: bit 1 of the launch's slot argument): nothing on the device needs the launch's record, so every
+// workgroup writes its partial record straight to pinned host memory -- [slot][workgroup][FTGP_METRIC_DOUBLES] -- and is done: no ticket, no
+// last workgroup, no barrier; the host adds the partial records up when the record is asked for (collect_slot() in ftgp_api.hip: integers,
+// exact in any order, bit-identical again).  That takes the hand-off's three dependent trips to memory out of every launch's tail.
 // called by ALL threads of the workgroup, after the state records have gone back to HBM; `scratch`: one int of LDS
+template <bool HOST_SUM>
 __device__ __forceinline__ void launch_metrics(const DeviceParams& P, const CarCore* cars_lds, const int64_t* steps_lds, int ncars_here, int ci0,
                                                unsigned char* scratch, double* partial /* [waves][FTGP_METRIC_DOUBLES] of LDS */, int slot, int wave)
 {
     int* last_flag = reinterpret_cast<int*>(scratch);
     const int lane = lane_id();
+    if (HOST_SUM && wave != 0) return;
     if (wave == 0) {                       // wave 0: one car per lane (a workgroup holds at most 16)
         double v[7] = { 0, 0, 0, 0, 0, INFINITY, -INFINITY };      // steps, laps, absolute completion, finished, off track, min / max lap time
         if (lane < ncars_here) {
@@ -1252,6 +1258,15 @@ __device__ __forceinline__ void launch_metrics(const DeviceParams& P, const CarC
         #pragma unroll
         for (int q = 0; q < 5; ++q) v[q] = wave_total_f64(v[q]);
         v[5] = wave_least_f64(v[5]); v[6] = wave_most_f64(v[6]);
+        if (HOST_SUM) {
+            if (lane == 0) {
+                double* mine = P.wg_metrics_host + ((size_t)slot * gridDim.x + blockIdx.x) * FTGP_METRIC_DOUBLES;
+                const double rec[FTGP_METRIC_DOUBLES] = { v[0], (double)ncars_here, v[1], v[2], v[3], v[4], v[5], v[6] };
+                #pragma unroll
+                for (int q = 0; q < FTGP_METRIC_DOUBLES; ++q) mine[q] = rec[q];
+            }
+            return;
+        }
         if (lane == 0) {
             // the one lane that publishes also counts: write-through (agent-scope) stores of the record, wait for them, then the ticket
             double* mine = P.wg_metrics + (size_t)blockIdx.x * FTGP_METRIC_DOUBLES;
@@ -1328,7 +1343,7 @@ __device__ __forceinline__ void stage16(void* dst, const void* src, int bytes)
 #endif
 // MULTI: several cars per env (inter-vehicle rays and contacts).  FAKE: FTGP_LIDAR_FAKELIDAR -- the sweep is lidar_fake() (its own
 // instantiation, so that the rangefinder kernels' code generation does not move).  metrics_slot: which of the two record slots this
-// launch's metrics go to (ftgp_metrics_allgather_begin / _end).
+// launch's metrics go to (ftgp_metrics_allgather_begin / _end); bit 1: the workgroups' partial records go to pinned host memory (launch_metrics).
 // ROSTER: `policy` may be FTGP_POLICY_PER_CAR (every car slot its own driver, ftgp_set_car_policies) -- again its own instantiation, so
 // that the single-driver kernels stay exactly what they were (the multi-car one lost 3 % to the run-time form of this test); the
 // FAKELIDAR kernels, which are for parity and not for throughput, exist in the ROSTER form only.
@@ -1476,8 +1491,11 @@ __global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(cons
         if (lane_here() == 0 && ci % P.cars_per_env == 0) P.steps[ci / P.cars_per_env] = L.steps[c];
     }
     if (P.wg_metrics) {                  // the scan windows and the centre line are dead now: the reduction's scratch
-        __syncthreads();
-        launch_metrics(P, L.cars, L.steps, ncars_here, ci0, lds + P.off_scan, reinterpret_cast<double*>(lds + P.off_path), metrics_slot, wave);
+        if (metrics_slot & 2) launch_metrics<true>(P, L.cars, L.steps, ncars_here, ci0, nullptr, nullptr, metrics_slot & 1, wave);      // (LDS state records: final since the last step's barrier)
+        else {
+            __syncthreads();
+            launch_metrics<false>(P, L.cars, L.steps, ncars_here, ci0, lds + P.off_scan, reinterpret_cast<double*>(lds + P.off_path), metrics_slot, wave);
+        }
     }
     FTGP_DIAG_WG_EXIT();
 }

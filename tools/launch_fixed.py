@@ -12,7 +12,7 @@ from ft_grandprix_amd.track import load_track
 policy = sys.argv[1] if len(sys.argv) > 1 else "fast"
 envs = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 lib = capi.load()
-tag = " ".join(k for k in ("FTGP_LAUNCH_PLAIN", "FTGP_NO_FUSED_METRICS") if os.environ.get(k)) or "default"
+tag = " ".join(k for k in ("FTGP_LAUNCH_PLAIN", "FTGP_NO_FUSED_METRICS", "FTGP_NO_HOST_SUM", "FTGP_WAIT_SPIN") if os.environ.get(k)) or "default"
 with capi.Env(lib, load_track("track"), n_envs=envs, n_rays=1080, spawn_mode=1, seed=1234) as e:
     e.rollout(policy, 200); e.last_kernel_ms()
     t = {1: [], 2: [], 3: [], 21: []}

@@ -7,6 +7,8 @@ cd "$(dirname "$0")/.."
 out=gpurun_out/launch_fixed.log
 mkdir -p gpurun_out
 python3 tools/launch_fixed.py fast 4096 > $out 2>&1
+FTGP_NO_HOST_SUM=1 python3 tools/launch_fixed.py fast 4096 >> $out 2>&1
+FTGP_WAIT_SPIN=1 python3 tools/launch_fixed.py fast 4096 >> $out 2>&1
 FTGP_LAUNCH_PLAIN=1 python3 tools/launch_fixed.py fast 4096 >> $out 2>&1
 FTGP_LAUNCH_PLAIN=1 FTGP_NO_FUSED_METRICS=1 python3 tools/launch_fixed.py fast 4096 >> $out 2>&1
 python3 tools/launch_fixed.py lobotomy 4096 >> $out 2>&1
