@@ -36,8 +36,8 @@ static_assert((FTGP_MAX_LAP_TIMES & (FTGP_MAX_LAP_TIMES - 1)) == 0, "the lap-tim
 // of the same step can run beside it.  The second half is what OTHER cars of the env need to see this car.
 struct alignas(16) LidarFrame {
     float u0, v0, chf, shf;       // LiDAR centre in pixels (binary32 of the binary64 value), heading (cos, sin) in binary32
-    double lcx, lcy;              // LiDAR centre, world
-    double x, y, qw, qz;          // pre-step pose
+    double lcx, lcy;              // LiDAR centre, world                         } FTGP_LIDAR_FAKELIDAR: i_x, i_y = the car's position in pixels
+    double x, y, qw, qz;          // pre-step pose                               } (custom.py:1382-1384) and x, y = heading (cos, sin) instead
     int32_t finished;
     int32_t slot0;                // first car slot (inside the workgroup) of this car's env      } multi-car envs only:
     float fx, fy;                 // binary32 of x, y: what the inter-vehicle cull compares        } see frame_write()

@@ -444,51 +444,113 @@ __device__ __forceinline__ void lidar_groups(const DeviceParams& P, ScalarParams
 //   march    raycast.py:9-20: while dt[int(y), int(x)] > 2 and 0 <= x <= W and 0 <= y <= H: advance by dt
 //   range    (distance / W) * s (custom.py:1392-1393), stored as binary32
 // int() truncates toward zero and a negative index wraps like numpy's; an index past the end -- the reference's IndexError --
-// ends the ray with range -1.  Rays are dealt to lanes statically (this mode is for parity, not for throughput); the ranges go
-// where lidar_groups() puts them: every range to HBM, the drivers' window to LDS as well.
-__device__ __forceinline__ void lidar_fake(ScalarParams G, const LidarFrame* frames, float* scan_rows, int ncars_here, int ci0, bool scan_lds, int wave, int nwaves)
+// ends the ray with range -1.
+//
+// march_fake(): the loop of raycast.py:12-17 for the 64 rays of a wave, hand-written like march_all() -- a ray leaves the loop by dropping
+// out of exec -- with the statement order kept and the tests reduced to what can differ:
+//   * numpy raises IndexError before the loop condition is looked at: an index is valid iff -n <= int(v) < n, i.e. (unsigned)(int(v) + n) < 2 n
+//     (`bad`: the ray reads -1);
+//   * a ray with x < 0 or y < 0 ends (its look-up, valid or wrapped, no longer matters: no load is issued for it); x <= W and y <= H need no
+//     test of their own: a ray that is still here has int(x) < W, int(y) < H;
+//   * what is left has 0 <= int(x) < W, 0 <= int(y) < H: one 24-bit multiply-add for the index, one 8-byte load (the table is
+//     L2-resident: hit rate 0.998, profiles/round5/fakelidar_r5base.log), `nearest > 2` by v_cmpx.
+// Binary64 throughout, one rounding per written operation (x += dx * nearest is a product and a sum).  `guard`: iterations after which a ray
+// is given up with what it has accumulated (a caller's fan may hold a zero direction: the reference would loop for ever).
+__device__ __forceinline__ void march_fake(double& x, double& y, double& dist, int& bad, double dx, double dy, int W, int H, const double* dt)
 {
-    const int R = G->n_rays, total = ncars_here * R, W = G->width, H = G->height, stride = G->ranges_stride;
+    double n = 0.0, t;
+    int xi, yi, a, b;
+    uint64_t sq, ex0;
+    int guard = 1 << 16;
+    asm volatile(
+        "s_mov_b64 %[ex0], exec\n"
+        "L_fake_loop_%=:\n\t"
+        "v_cvt_i32_f64_e32 %[xi], %[x]\n\t"                              // int(x): truncation toward zero
+        "v_cvt_i32_f64_e32 %[yi], %[y]\n\t"
+        "v_add_u32_e32 %[a], %[W], %[xi]\n\t"
+        "v_add_u32_e32 %[b], %[H], %[yi]\n\t"
+        "v_cmp_le_u32_e32 vcc, %[W2], %[a]\n\t"                          // IndexError: not (-W <= int(x) < W) ...
+        "v_cmp_le_u32_e64 %[sq], %[H2], %[b]\n\t"                        // ... or not (-H <= int(y) < H)
+        "s_or_b64 vcc, vcc, %[sq]\n\t"
+        "v_cndmask_b32_e64 %[bad], %[bad], -1, vcc\n\t"
+        "v_cmp_gt_f64_e64 %[sq], 0, %[x]\n\t"                            // 0 <= x fails
+        "s_or_b64 vcc, vcc, %[sq]\n\t"
+        "v_cmp_gt_f64_e64 %[sq], 0, %[y]\n\t"
+        "s_or_b64 vcc, vcc, %[sq]\n\t"
+        "s_andn2_b64 exec, exec, vcc\n\t"                                // those rays are done
+        "s_cbranch_execz L_fake_done_%=\n\t"
+        "v_mad_u32_u24 %[a], %[yi], %[W], %[xi]\n\t"
+        "v_lshlrev_b32_e32 %[a], 3, %[a]\n\t"
+        "global_load_dwordx2 %[n], %[a], %[dt]\n\t"
+        "s_sub_u32 %[guard], %[guard], 1\n\t"
+        "s_cbranch_scc1 L_fake_done_%=\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        "v_cmpx_lt_f64_e32 vcc, 2.0, %[n]\n\t"                           // while nearest > eps
+        "s_cbranch_execz L_fake_done_%=\n\t"
+        "v_add_f64 %[dist], %[dist], %[n]\n\t"                           // distance += nearest
+        "v_mul_f64 %[t], %[dx], %[n]\n\t"
+        "v_add_f64 %[x], %[x], %[t]\n\t"                                 // x += dx * nearest
+        "v_mul_f64 %[t], %[dy], %[n]\n\t"
+        "v_add_f64 %[y], %[y], %[t]\n\t"                                 // y += dy * nearest
+        "s_branch L_fake_loop_%=\n"
+        "L_fake_done_%=:\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        "s_mov_b64 exec, %[ex0]"
+        : [x] "+v"(x), [y] "+v"(y), [dist] "+v"(dist), [bad] "+v"(bad), [n] "+v"(n), [t] "=&v"(t), [xi] "=&v"(xi), [yi] "=&v"(yi), [a] "=&v"(a), [b] "=&v"(b),
+          [sq] "=&s"(sq), [ex0] "=&s"(ex0), [guard] "+s"(guard)
+        : [dx] "v"(dx), [dy] "v"(dy), [W] "s"(W), [H] "s"(H), [W2] "s"(2 * W), [H2] "s"(2 * H), [dt] "s"(dt)
+        : "vcc", "scc", "memory");
+}
+
+// The FAKELIDAR sweep of one step for all cars of the workgroup: the task list, the draw and the delivery of lidar_groups() -- groups of 64
+// neighbouring rays of one car, long-first across the workgroup's cars, a pair's two groups one after the other -- around march_fake().
+// What depends on the car alone -- i_x, i_y (two binary64 divisions) and the heading -- comes with its LiDAR frame (frame_write).
+__device__ __forceinline__ void lidar_fake(ScalarParams G, const LidarFrame* frames, float* scan_rows, int* pool, int ncars_here, int ci0, bool scan_lds)
+{
+    typedef __attribute__((address_space(1))) float* global_f32;
+    typedef __attribute__((address_space(1))) unsigned char* global_u8w;
+    const int R = G->n_rays, half = R >> 1, cpb = G->cars_per_block, ntasks = cpb * G->tasks_per_car;
+    const int W = G->width, H = G->height, stride = G->ranges_stride;
+    const uint32_t gmagic = G->group_magic;
     const int eighth = G->eighth, win_floats = G->win_floats;
-    const uint32_t magic = G->ray_magic;
     const double s = G->map_size;
-    const double* __restrict__ dt = G->edt;
+    const double* dt = G->edt;
     const double* __restrict__ fan = G->fan_dirs;
-    float* ranges = G->ranges + (size_t)ci0 * stride;
-    for (int g = wave * FTGP_WAVE + lane_here(); g < total; g += nwaves * FTGP_WAVE) {
-        const int c = (int)__umulhi((uint32_t)g, magic), j = g - c * R;
-        const LidarFrame* f = frames + c;
-        const double qw = f->qw, qz = f->qz;
-        const double ch = 1.0 - 2.0 * (qz * qz), sh = 2.0 * (qw * qz);
-        const double bx = fan[2 * j], by = fan[2 * j + 1];
-        const double dxw = ch * bx - sh * by, dyw = sh * bx + ch * by;
-        const double dx = dxw, dy = -dyw;
-        double x = (f->x / s) * (double)W, y = -(f->y / s) * (double)H;
-        double distance = 0.0;
-        bool bad = false;
-        long yi = (long)y, xi = (long)x;                          // int(): truncation toward zero
-        if (yi < 0) yi += H;
-        if (xi < 0) xi += W;                                      // numpy negative-index wrap
-        double nearest = 0.0;
-        if (yi < 0 || yi >= H || xi < 0 || xi >= W) bad = true; else nearest = dt[(size_t)yi * W + xi];
-        for (int guard = 0; guard < (1 << 20) && !bad && nearest > 2.0 && 0 <= x && x <= W && 0 <= y && y <= H; ++guard) {
-            distance += nearest;
-            x += dx * nearest;
-            y += dy * nearest;
-            yi = (long)y; xi = (long)x;
-            if (yi < 0) yi += H;
-            if (xi < 0) xi += W;
-            if (yi < 0 || yi >= H || xi < 0 || xi >= W) { bad = true; break; }
-            nearest = dt[(size_t)yi * W + xi];
-        }
-        const float r = bad ? -1.0f : (float)((distance / (double)W) * s);
-        const int jw = j - eighth;
-        const bool in_window = (unsigned)jw < (unsigned)(R - 2 * eighth);
-        ranges[(size_t)c * stride + j] = r;
-        if (scan_lds) {
-            float* row = scan_rows + c * win_floats;
-            if (in_window) row[(eighth & 3) + jw] = r;
-            if (j == 0) row[win_floats - 1] = r;
+    const global_f32 ranges = (global_f32)G->ranges + (size_t)ci0 * stride;
+    const int lane = lane_here();
+    for (int round = 0; round < (1 << 16); ++round) {          // (bounded: a safety net)
+        int g = 0;
+        if (lane == 0) g = atomicAdd(pool, 1);
+        g = __builtin_amdgcn_readfirstlane(g);
+        if (g >= ntasks) break;
+        const int kidx = gmagic ? (int)__umulhi((uint32_t)g, gmagic) : g, c = g - kidx * cpb;
+        const int ent = G->group_order[kidx];                     // first ray | kind << 16 (wave-uniform): see lidar_groups()
+        const int j0 = ent & 0xffff, kind = ent >> 16;
+        int j; bool mine;
+        if (kind == 2) { j = j0 + (lane & 31) + (lane >= 32 ? half : 0); mine = (lane & 31) < half - j0; }
+        else { j = j0 + lane; mine = j < (kind == 1 ? half : R); }
+        mine = mine && c < ncars_here;
+        for (int pass = 0; pass < (kind == 1 ? 2 : 1); ++pass, j += half) {
+            if (!mine) continue;
+            const LidarFrame* f = frames + c;
+            float r = 0.0f;                                       // a finished car's rangefinders are switched off (custom.py:1436-1439): its scan reads 0
+            if (!f->finished) {
+                const double ch = f->x, sh = f->y;                // FAKELIDAR frames: heading (cos, sin) in binary64 (frame_write)
+                const double bx = fan[2 * j], by = fan[2 * j + 1];
+                const double dxw = ch * bx - sh * by, dyw = sh * bx + ch * by;
+                double x = f->lcx, y = f->lcy, distance = 0.0;    // FAKELIDAR frames: i_x, i_y (custom.py:1383-1384)
+                int bad = 0;
+                march_fake(x, y, distance, bad, dxw, -dyw, W, H, dt);      // image rows grow downwards
+                r = bad ? -1.0f : (float)((distance / (double)W) * s);     // ranges /= original_width; ranges *= s (custom.py:1392-1393)
+            }
+            *(global_f32)((global_u8w)(ranges + c * stride) + ((uint32_t)j << 2)) = r;
+            if (scan_lds) {
+                const int jw = j - eighth;
+                const bool in_window = (unsigned)jw < (unsigned)(R - 2 * eighth);
+                float* row = scan_rows + c * win_floats;
+                if (in_window) row[(eighth & 3) + jw] = r;
+                if (j == 0) row[win_floats - 1] = r;
+            }
         }
     }
 }
@@ -730,6 +792,10 @@ __device__ __forceinline__ bool frame_write(const DeviceParams& P, const FtgpVeh
     fr->chf = (float)ch; fr->shf = (float)sh;
     fr->lcx = lcx; fr->lcy = lcy;
     fr->x = st->x; fr->y = st->y; fr->qw = qw; fr->qz = qz;
+    if (sgpr(P.lidar_mode) == FTGP_LIDAR_FAKELIDAR) {          // what lidar_fake() needs of the car: i_x, i_y (custom.py:1382-1384) and the heading, binary64
+        fr->lcx = (st->x / P.map_size) * (double)P.width; fr->lcy = -(st->y / P.map_size) * (double)P.height;
+        fr->x = ch; fr->y = sh;
+    }
     fr->finished = finished;
     if (sgpr(P.cars_per_env) > 1) {       // what the inter-vehicle cull reads (this function sits on the driver -> dynamics chain: nothing it does not need)
         fr->slot0 = slot - slot % P.cars_per_env;
@@ -1470,7 +1536,7 @@ __global__ void __launch_bounds__(1024, FTGP_WAVES_PER_EU) ftgp_step_kernel(cons
             const LdsOffsets off = lds_offsets(G);
             const DeviceParams& P = *reinterpret_cast<const DeviceParams*>(lds + off.params);
             const Lds L = lds_view(off, lds);
-            if (FAKE) lidar_fake(G, L.frame + par * cpb, L.scan + par * cpb * G->win_floats, ncars_here, ci0, need_scan, wave, nwaves);
+            if (FAKE) lidar_fake(G, L.frame + par * cpb, L.scan + par * cpb * G->win_floats, L.pool + par, ncars_here, ci0, need_scan);
             else lidar_groups<MULTI>(P, G, L, L.frame + par * cpb, L.pairs + par * cpb * FTGP_PAIR_STRIDE, L.mmask + par * cpb * G->mmask_stride, L.scan + par * cpb * G->win_floats,
                                      L.pool + par, ncars_here, ci0, need_scan, second_half STAMP_PASS);
         }

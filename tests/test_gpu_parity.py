@@ -578,6 +578,15 @@ def test_metrics_exchange_in_two_halves_beside_the_next_launch(product, with_com
         g.metrics_allgather_begin()
         np.testing.assert_array_equal(g.metrics_allgather_end()[0], twin.metrics_local())
         np.testing.assert_array_equal(g.lidar(), twin.lidar())
+        # an exchange promises the record of the state at its begin, whatever refreshes the slot before its end: begin ->
+        # reset -> ftgp_metrics_local (the metrics kernel writes the post-reset record) -> end still delivers the pre-reset one
+        g.rollout("nidc", 25); twin.rollout("nidc", 25)
+        before = twin.metrics_local()
+        g.metrics_allgather_begin()
+        g.reset(); twin.reset()
+        np.testing.assert_array_equal(g.metrics_local(), twin.metrics_local())             # the post-reset state: steps 0
+        assert g.metrics_local()[0] == 0 and before[0] == 8 * 25
+        np.testing.assert_array_equal(g.metrics_allgather_end()[0], before)
 
 
 def test_bench_repeats_median_and_overlap_fields(product):
@@ -786,19 +795,25 @@ def test_launch_metrics_record_equals_the_metrics_kernel(product, oracle):
     import os
     t = load_track("circle")
     kw = dict(n_envs=37, n_rays=90, lap_target=1, spawn_mode=1, seed=7)
-    g = capi.Env(product, t, **kw)
+    g = capi.Env(product, t, **kw)                       # one rank, no communicator: partial records to pinned memory, added up by the host
     os.environ["FTGP_NO_FUSED_METRICS"] = "1"
     try:
         k = capi.Env(product, t, **kw)
     finally:
         del os.environ["FTGP_NO_FUSED_METRICS"]
+    os.environ["FTGP_NO_HOST_SUM"] = "1"                 # the device-side hand-off (what a rank with a communicator runs)
+    try:
+        d = capi.Env(product, t, **kw)
+    finally:
+        del os.environ["FTGP_NO_HOST_SUM"]
     o = capi.Env(oracle, t, **kw)
     oracle.dll.oracle_set_threads(o.h, 8)
-    with g, k, o:
+    with g, k, d, o:
         for n in (1, 250, 9000, 10000):
-            for e in (g, k, o):
+            for e in (g, k, d, o):
                 e.rollout("nidc", n)
             np.testing.assert_array_equal(g.metrics_local(), k.metrics_local())
+            np.testing.assert_array_equal(d.metrics_local(), k.metrics_local())
             np.testing.assert_array_equal(g.metrics_local(), o.metrics_local())
             np.testing.assert_array_equal(g.metrics_allgather()[0], k.metrics_local())
         assert g.metrics_local()[4] > 0 and np.isfinite(g.metrics_local()[6])          # some cars finished: lap times in the record
