@@ -40,8 +40,13 @@ from ft_grandprix_amd.track import load_track  # noqa: E402
 ALGO_BYTES_PER_ENV_STEP = lambda n_rays, cars: cars * (4 * n_rays + 832)   # 5152 B at R = 1080
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_MEASURED_COPY_GBS = 6290.0
-N_SIMD = 256 * 4               # MI355X: 256 CUs x 4 SIMD-32; a wave64 VALU instruction issues over 2 cycles on one SIMD
-PROFILE_DIRS = [os.path.join(ROOT, "profiles", d) for d in ("round4", "round3", "round2")]     # newest first
+N_SIMD = 256 * 4               # MI355X: 256 CUs x 4 SIMDs
+# What a wave64 vector instruction costs a SIMD at 8 waves per SIMD, measured with tools/issue_calib.sh (profiles/round5/issue_calib.log):
+# SIMD-cycles per instruction of the kind.  SQ_ACTIVE_INST_VALU is NOT a cycle count: it ticks once per vector instruction (twice for a
+# transcendental), so round 4's "busy" figure (that counter x 4) was an instruction count in disguise and could exceed 1.
+VALU_CYCLES_CHEAPEST = 2.28    # v_add_u32 (and logic / shift / move): no vector instruction issues faster
+VALU_CYCLES_DEAREST = 4.32     # v_cmp / v_cndmask / conversions / binary64 (v_fma_f32: 3.56); only v_rcp_f32 (8.1, two per ray set-up) costs more
+PROFILE_DIRS = [os.path.join(ROOT, "profiles", d) for d in ("round5", "round4", "round3", "round2")]     # newest first
 
 
 def kernel_source_sha():
@@ -272,6 +277,11 @@ def main():
     metrics = timed["records"]
     walls, kmss = np.asarray(timed["wall_s"]), np.asarray(timed["kernel_ms"])
     barrier()
+    # what every rank saw, before the max over ranks is taken: a scaling curve that bends can then be read -- one slow rank, a slow
+    # exchange, or all ranks alike (DESIGN.md section 7 says what the design predicts: flat)
+    ends = np.asarray(timed["exchange_end_s"] or [0.0])
+    mine = np.array([float(np.median(kmss)), float(kmss.min()), float(kmss.max()), float(np.median(walls)) * 1e3, float(np.median(ends)) * 1e3, float(ends.max()) * 1e3])
+    per_rank = rdzv.all_gather(mine) if rdzv is not None else mine[None, :]
     if rdzv is not None:
         both = rdzv.max(np.concatenate([walls, kmss]))               # per launch: the max over ranks
         walls, kmss = both[:repeats], both[repeats:]
@@ -305,24 +315,33 @@ def main():
             c, steps_c = sq["counters"], sq["steps"]
             valu_per_car_step = c["SQ_INSTS_VALU"] / (sq["n_envs"] * sq.get("cars", 1) * steps_c)
             cycles = c["GRBM_GUI_ACTIVE"] / 8.0                         # the counter sums the 8 XCDs
+            per_simd = c["SQ_INSTS_VALU"] / (N_SIMD * cycles)            # vector instructions per SIMD-cycle
             roof["valu"] = {"insts_per_car_step": valu_per_car_step,
-                            "issue_frac": c["SQ_INSTS_VALU"] * 2.0 / (N_SIMD * cycles),      # of one wave64 VALU op per 2 cycles per SIMD
-                            "busy_frac": c["SQ_ACTIVE_INST_VALU"] * 4.0 / (N_SIMD * cycles),  # SQ_ACTIVE_INST_VALU counts quad-cycles per wave
+                            # the vector pipe's occupancy lies between these two (every instruction priced at the cheapest / the dearest kind of
+                            # the calibration); both are fractions of the SIMD-cycles and the upper one is capped at 1
+                            "pipe_occupancy_lower": per_simd * VALU_CYCLES_CHEAPEST,
+                            "pipe_occupancy_upper": min(1.0, per_simd * VALU_CYCLES_DEAREST),
+                            "waves_waiting_frac": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"] if "SQ_WAIT_ANY" in c and c.get("SQ_WAVE_CYCLES") else None,
+                            "waves_waiting_for_issue_frac": c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"] if "SQ_WAIT_INST_ANY" in c and c.get("SQ_WAVE_CYCLES") else None,
+                            "calibration": "profiles/round5/issue_calib.log",
                             "shader_clock_ghz": cycles / (sq["kernel_ms"] * 1e6) if sq.get("kernel_ms") else None,
                             "source": {"file": sq["file"], "measured_in_this_run": False,
                                        "kernel_source_sha": sq.get("kernel_source_sha"), "stale": sq["stale"]}}
         if "valu" in roof:
-            # the vector pipes against their own peak, beside the HBM figure: one wave64 instruction per 2 cycles and SIMD is the issue peak
+            # the vector pipes against their own peak, beside the HBM figure.  `bound` is "valu-issue" when even the LOWER bound of the pipe's
+            # occupancy is above half of the SIMD-cycles while the fabric carries a small part of the HBM peak, and the waves do queue for issue
             v = roof["valu"]
-            roof["frac_valu_issue"], roof["frac_valu_busy"] = v["issue_frac"], v["busy_frac"]
+            roof["frac_valu_pipe_lower"], roof["frac_valu_pipe_upper"] = v["pipe_occupancy_lower"], v["pipe_occupancy_upper"]
             fabric = roof.get("measured_traffic_gbs", achieved) / HBM_PEAK_GBS
-            if v["busy_frac"] >= 0.6 and v["busy_frac"] > 2.0 * fabric:
+            if v["pipe_occupancy_lower"] >= 0.5 and v["pipe_occupancy_lower"] > 2.0 * fabric:
                 roof["bound"] = "valu-issue"
-            roof["limiter"] = (f"vector-instruction issue: the SIMDs' vector pipes are busy {100 * v['busy_frac']:.0f} % of the time "
-                               f"(frac_valu_busy) at {100 * v['issue_frac']:.0f} % of the 2-cycle issue peak (frac_valu_issue: the instructions cost 2-4 "
-                               f"cycles each); the fabric traffic is {100 * fabric:.0f} % of the HBM peak"
+            wait = v.get("waves_waiting_for_issue_frac")
+            roof["limiter"] = (f"vector-instruction issue: {v['insts_per_car_step']:.0f} wave64 vector instructions per car-step occupy the SIMDs' vector pipes "
+                               f"{100 * v['pipe_occupancy_lower']:.0f} - {100 * v['pipe_occupancy_upper']:.0f} % of the time (each priced at {VALU_CYCLES_CHEAPEST} - "
+                               f"{VALU_CYCLES_DEAREST} cycles, tools/issue_calib.sh)" + (f", waves wait for an issue slot {100 * wait:.0f} % of their life" if wait is not None else "")
+                               + f"; the fabric traffic is {100 * fabric:.0f} % of the HBM peak"
                                if roof["bound"] == "valu-issue" else
-                               f"HBM / fabric traffic at {100 * fabric:.0f} % of the peak; vector pipes busy {100 * v['busy_frac']:.0f} %")
+                               f"HBM / fabric traffic at {100 * fabric:.0f} % of the peak; vector pipes occupied {100 * v['pipe_occupancy_lower']:.0f} - {100 * v['pipe_occupancy_upper']:.0f} %")
         out = {
             "metric": "env-steps/sec (4096 envs, 1080-ray LiDAR) at 1/2/4/8 MI355X; HBM roofline %",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -337,7 +356,14 @@ def main():
                        "policy": args.policy, "steps_per_launch": args.steps, "parallelism": f"env-shard x{world}"},
             "roofline": roof,
             "metrics_allgather": {"collective": collective, "ranks": int(metrics.shape[0]), "sum_laps": float(metrics[:, 2].sum()),
-                                  "sum_steps": float(metrics[:, 0].sum())},
+                                  "sum_steps": float(metrics[:, 0].sum()),
+                                  # how long collecting an exchange (end()) held up a launch's host side: median and worst, worst rank
+                                  "end_wait_ms_median": float(per_rank[:, 4].max()), "end_wait_ms_max": float(per_rank[:, 5].max())},
+            # per rank, before the max over ranks: kernel time of a launch (HIP events: median / min / max over the timed launches) and the
+            # median wall time -- what explains a scaling curve that is not flat
+            "per_rank": {"kernel_ms_median": [float(x) for x in per_rank[:, 0]], "kernel_ms_min": [float(x) for x in per_rank[:, 1]],
+                         "kernel_ms_max": [float(x) for x in per_rank[:, 2]], "wall_ms_median": [float(x) for x in per_rank[:, 3]],
+                         "kernel_ms_spread_over_ranks": float(per_rank[:, 0].max() / max(per_rank[:, 0].min(), 1e-12))},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(track, args.rays, args.policy, args.cars, seed, lidar_mode=args.lidar)

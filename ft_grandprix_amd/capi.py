@@ -75,7 +75,7 @@ API_SYMBOLS = (
     "rollout", "set_car_policies", "get_lidar", "get_snapshot", "get_pose", "get_progress", "get_winners", "get_lap_times", "get_ctrl",
     "get_steps", "set_pose", "policy_eval", "eval_progress", "metrics_local", "comm_unique_id", "comm_init", "metrics_allgather",
     "metrics_allgather_begin", "metrics_allgather_end", "get_distance_field",
-    "last_kernel_ms", "kernel_name", "fakelidar", "selftest", "build_info",
+    "last_kernel_ms", "kernel_name", "fakelidar", "selftest", "build_info", "get_race_steps",
 )
 
 
@@ -127,6 +127,7 @@ class CLib:
             "get_winners": (i32, [vp, dp]),
             "get_lap_times": (i32, [vp, dp, dp]),
             "get_ctrl": (i32, [vp, dp]),
+            "get_race_steps": (i32, [vp, dp]),
             "get_steps": (i32, [vp, dp]),
             "set_pose": (i32, [vp, dp]),
             "policy_eval": (i32, [vp, i32, dp, dp]),
@@ -324,6 +325,13 @@ class Env:
         self._call("get_lap_times", _ptr(counts), _ptr(times))
         return counts, times
 
+    def race_steps(self) -> np.ndarray:
+        """int64 [n_cars, 2] = (start, finish_step): vehicle_state.start (custom.py:1362) and the step at which `finished` was set (-1 while
+        racing), with all 64 bits of self.steps (columns 6 and 9 of ``progress()`` saturate at 2**31 - 1)."""
+        out = np.empty((self.n_cars, 2), dtype=np.int64)
+        self._call("get_race_steps", _ptr(out))
+        return out
+
     def ctrl(self) -> np.ndarray:
         out = np.empty((self.n_cars, 2), dtype=np.float64)
         self._call("get_ctrl", _ptr(out))
@@ -382,7 +390,8 @@ def lap_time_list(count: int, ring: np.ndarray) -> list:
     count <= MAX_LAP_TIMES, the newest MAX_LAP_TIMES after that."""
     count = int(count)
     first = max(0, count - MAX_LAP_TIMES)
-    return [float(ring[k % MAX_LAP_TIMES]) for k in range(first, count)]
+    # (a slot that reads NaN holds no entry: a backward crossing popped the lap time that had overwritten it, see include/ftgp.h)
+    return [float(ring[k % MAX_LAP_TIMES]) for k in range(first, count) if ring[k % MAX_LAP_TIMES] == ring[k % MAX_LAP_TIMES]]
 
 
 def fakelidar(lib: CLib, dt: np.ndarray, origins: np.ndarray, cosines: np.ndarray, sines: np.ndarray, eps: float = 2.0,

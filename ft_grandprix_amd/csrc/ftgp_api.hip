@@ -570,13 +570,14 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
         const double phi = ((360.0 / (double)cfg->n_rays) * (double)j - 90.0) * (M_PI / 180.0);
         fan[2 * (size_t)j] = cfg->fan_dirs ? cfg->fan_dirs[2 * (size_t)j] : sin(phi);
         fan[2 * (size_t)j + 1] = cfg->fan_dirs ? cfg->fan_dirs[2 * (size_t)j + 1] : -cos(phi);
-        // The rangefinders' own fan is point-symmetric: site j + n/2 looks exactly opposite to site j.  The table says so to the last bit
-        // (the second half is the negated first half -- libm's sin / cos of phi + pi need not be), which is what lets the sweep derive a
-        // ray from its opposite; a caller's fan_dirs is taken as it comes.
-        if (!cfg->fan_dirs && cfg->n_rays % 2 == 0 && j >= cfg->n_rays / 2) {
-            fan[2 * (size_t)j] = -fan[2 * (size_t)(j - cfg->n_rays / 2)]; fan[2 * (size_t)j + 1] = -fan[2 * (size_t)(j - cfg->n_rays / 2) + 1];
-        }
         ray[2 * (size_t)j] = (float)fan[2 * (size_t)j]; ray[2 * (size_t)j + 1] = (float)fan[2 * (size_t)j + 1];
+        // The rangefinders' own fan is point-symmetric: site j + n/2 looks exactly opposite to site j.  The BINARY32 table says so to the last
+        // bit (its second half is the negated first half -- the roundings of libm's sin / cos of phi + pi need not be), which is what lets the
+        // sweep derive a ray from its opposite; a caller's fan_dirs is taken as it comes.  The binary64 fan of FAKELIDAR mode is libm's value
+        // for every site, as include/ftgp.h says for fan_dirs == NULL (round 4 negated it too: a last-bit difference from the documented fan).
+        if (!cfg->fan_dirs && cfg->n_rays % 2 == 0 && j >= cfg->n_rays / 2) {
+            ray[2 * (size_t)j] = -ray[2 * (size_t)(j - cfg->n_rays / 2)]; ray[2 * (size_t)j + 1] = -ray[2 * (size_t)(j - cfg->n_rays / 2) + 1];
+        }
     }
     {   // the sweep's work list (lidar_groups): draw g -> (kidx = g / cars_per_block, car slot = g % cars_per_block), task = group_order[kidx]
         const int R = cfg->n_rays, halfR = R / 2;
@@ -932,10 +933,11 @@ int ftgp_get_winners(FtgpEnv* e, int32_t* out)
             int place = 0;
             if (p[i * FTGP_PROGRESS_INTS + 4]) {
                 place = 1;
-                const int32_t mine = p[i * FTGP_PROGRESS_INTS + 9];
+                auto fin64 = [&](int k) { int64_t v; memcpy(&v, e->h_core.data() + ((size_t)env * cpe + k) * kCoreDoubles + 15, sizeof v); return v; };      // all 64 bits
+                const int64_t mine = fin64(i);
                 for (int k = 0; k < cpe; ++k)
                     if (k != i && p[k * FTGP_PROGRESS_INTS + 4]) {
-                        const int32_t theirs = p[k * FTGP_PROGRESS_INTS + 9];
+                        const int64_t theirs = fin64(k);
                         if (theirs < mine || (theirs == mine && k < i)) ++place;
                     }
             }
@@ -954,6 +956,17 @@ int ftgp_get_lap_times(FtgpEnv* e, int32_t* counts, double* times)
                             
                              sizeof(double) * FTGP_MAX_LAP_TIMES, (size_t)e->P.n_cars, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+int ftgp_get_race_steps(FtgpEnv* e, int64_t* out)
+{
+    if (!e || !out) return fail(FTGP_ERR_ARG, "null argument%s");
+    if (int rc = sync_rows_to_host(e)) return rc;
+    for (int i = 0; i < e->P.n_cars; ++i) {          // the pack kernel ships the two int64 as bit patterns in the row's last two doubles
+        memcpy(out + 2 * (size_t)i, e->h_core.data() + (size_t)i * kCoreDoubles + 14, sizeof(int64_t));
+        memcpy(out + 2 * (size_t)i + 1, e->h_core.data() + (size_t)i * kCoreDoubles + 15, sizeof(int64_t));
+    }
     return 0;
 }
 

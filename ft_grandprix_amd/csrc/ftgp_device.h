@@ -18,11 +18,10 @@ struct alignas(16) CarCore {
     double u_speed, u_steer;      // controls
     double last_steer;            // fast.py:12
     double dist2;                 // squared distance to the centre-line (custom.py:1343)
-    int32_t completion, laps, start, offset;
+    int32_t completion, laps, offset, n_times;
     int32_t good_start, finished, off_track, delta;
-    int32_t n_times;
-    int32_t finish_step;          // env step at which `finished` was set (custom.py:1367-1370); meaningful while finished != 0
-    int32_t pad1, pad2;
+    int64_t start;                // env step of the last counted line crossing (vehicle_state.start, custom.py:1362): 64 bits like self.steps
+    int64_t finish_step;          // env step at which `finished` was set (custom.py:1367-1370); meaningful while finished != 0
 };
 // The lap-time list stays in HBM (written on lap crossings only).
 struct alignas(16) CarState : CarCore {

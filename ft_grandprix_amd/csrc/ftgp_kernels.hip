@@ -577,7 +577,7 @@ __global__ void ftgp_selftest_rcp_kernel(unsigned long long* __restrict__ mismat
 // =============================================================================================
 // K3: lap progress (custom.py:1340-1372)
 // =============================================================================================
-struct Race { int32_t completion, laps, start, offset, good_start, finished, off_track, delta, n_times, finish_step; double dist2; };
+struct Race { int32_t completion, laps, offset, good_start, finished, off_track, delta, n_times; int64_t start, finish_step; double dist2; };
 
 __device__ __forceinline__ void progress_update(const DeviceParams& P, Race& s, int64_t steps, int closest, double best, double* __restrict__ times)
 {
@@ -588,23 +588,28 @@ __device__ __forceinline__ void progress_update(const DeviceParams& P, Race& s, 
     const int delta = completion - s.completion;
     s.delta = (((completion - s.completion + 50) % 100) + 100) % 100 - 50;
     if (abs(delta) > 90) {
-        const double lap_time = (double)(steps - (int64_t)s.start) * P.dt;
+        const double lap_time = (double)(steps - s.start) * P.dt;
         if (s.delta < 0) {                                // backwards across the line, custom.py:1352-1356
             s.laps -= 1;
             s.good_start = 0;
-            if (s.n_times != 0) s.n_times -= 1;
+            if (s.n_times != 0) {                             // times.pop()
+                // the ring keeps the newest FTGP_MAX_LAP_TIMES: beyond that the popped entry sits in the slot of the oldest one the list would
+                // still show (it was overwritten when the popped lap was appended) -- that slot is marked empty (NaN: skipped by every reader)
+                if (s.n_times > FTGP_MAX_LAP_TIMES) times[(s.n_times - 1) & (FTGP_MAX_LAP_TIMES - 1)] = __longlong_as_double(0x7ff8000000000000ll);
+                s.n_times -= 1;
+            }
         } else if (s.delta > 0) {                         // custom.py:1357-1366
             if (s.good_start) {
                 times[s.n_times & (FTGP_MAX_LAP_TIMES - 1)] = lap_time;      // times.append(lap_time): a ring of the newest FTGP_MAX_LAP_TIMES
                 s.n_times += 1;
-                s.start = (int32_t)steps;
+                s.start = steps;
             }
             s.laps += 1;
             s.good_start = 1;
         }
     }
     if (s.laps >= P.lap_target) {                         // custom.py:1367-1370; the step of the first time orders the winners (custom.py:1368-1369)
-        if (!s.finished) s.finish_step = steps > 0x7fffffffll ? 0x7fffffff : (int32_t)steps;      // the progress row is int32: saturates after 2^31 - 1 steps
+        if (!s.finished) s.finish_step = steps;
         s.finished = 1;
     }
     s.completion = completion;
@@ -1683,7 +1688,7 @@ __global__ void ftgp_set_pose_kernel(DeviceParams P, const double* __restrict__ 
 
 // Packed read-back rows, one car per lane: the host copies 3 small arrays instead of the whole state records.
 //   prog  int32[n_cars][FTGP_PROGRESS_INTS]   (custom.py:91-143: lap_completion / absolute_completion folded in)
-//   core  double[n_cars][16]: x y qw qz vx vy wz u_speed u_steer laps lap_completion absolute_completion steps n_times 0 0
+//   core  double[n_cars][16]: x y qw qz vx vy wz u_speed u_steer laps lap_completion absolute_completion steps n_times start finish_step (the last two: int64 bit patterns)
 __global__ void ftgp_pack_kernel(DeviceParams P, int32_t* __restrict__ prog, double* __restrict__ core)
 {
     const int ci = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1692,10 +1697,14 @@ __global__ void ftgp_pack_kernel(DeviceParams P, int32_t* __restrict__ prog, dou
     const int lc = a.good_start ? a.completion : -(100 - a.completion);         // custom.py:132-140
     int32_t* o = prog + (size_t)ci * FTGP_PROGRESS_INTS;
     o[0] = a.laps; o[1] = a.completion; o[2] = lc; o[3] = a.laps * 100 + lc; o[4] = a.finished;   // custom.py:142-143
-    o[5] = a.off_track; o[6] = a.start; o[7] = a.good_start; o[8] = a.delta; o[9] = a.finished ? a.finish_step : -1;
+    // the row is int32 while steps are int64: start and finish_step saturate at 2^31 - 1 here (ftgp_get_race_steps has all 64 bits)
+    const int64_t top = 0x7fffffffll;
+    o[5] = a.off_track; o[6] = (int32_t)(a.start > top ? top : a.start); o[7] = a.good_start; o[8] = a.delta;
+    o[9] = a.finished ? (int32_t)(a.finish_step > top ? top : a.finish_step) : -1;
     double* d = core + (size_t)ci * 16;
     d[0] = a.x; d[1] = a.y; d[2] = a.qw; d[3] = a.qz; d[4] = a.vx; d[5] = a.vy; d[6] = a.wz; d[7] = a.u_speed; d[8] = a.u_steer;
-    d[9] = a.laps; d[10] = lc; d[11] = a.laps * 100 + lc; d[12] = (double)P.steps[ci / P.cars_per_env]; d[13] = a.n_times; d[14] = d[15] = 0.0;
+    d[9] = a.laps; d[10] = lc; d[11] = a.laps * 100 + lc; d[12] = (double)P.steps[ci / P.cars_per_env]; d[13] = a.n_times;
+    d[14] = __longlong_as_double(a.start); d[15] = __longlong_as_double(a.finished ? a.finish_step : -1ll);      // bit patterns of the two int64 (ftgp_get_race_steps)
 }
 
 // fakelidar-compat (raycast.py:5-21): one ray per lane, binary64, same operation order as the Python loop.

@@ -119,16 +119,19 @@ def run_timed(env: capi.Env, policy, steps: int, repeats: int, exchange, barrier
     launch k + 1's, after that launch has been enqueued: it overlaps the next launch instead of sitting serially between two
     (an exchange begun before the call -- the warm-up's -- is collected during the first launch).  The last launch's exchange is
     collected after the loop.  ``kernel_ms()`` (default ``env.last_kernel_ms``) is what synchronises with a launch.
-    Returns {"wall_s": [...], "kernel_ms": [...], "records": the newest collected records}."""
+    Returns {"wall_s": [...], "kernel_ms": [...], "exchange_end_s": [how long each collected exchange's end() took], "records": the
+    newest collected records}."""
     sync = kernel_ms if kernel_ms is not None else env.last_kernel_ms
-    walls, kms, records = [], [], None
+    walls, kms, ends, records = [], [], [], None
     for _ in range(repeats):
         if barrier is not None:
             barrier()
         t0 = time.perf_counter()
         env.rollout(policy, steps)                       # enqueued: returns at once on the GPU
         if exchange.open:
+            te = time.perf_counter()
             records = exchange.end()                     # the previous launch's exchange (it ran beside this enqueue / launch)
+            ends.append(time.perf_counter() - te)        # what end() made this launch's host side wait (an exchange that overlapped: next to nothing)
         if not exchange.after_sync:
             exchange.begin()                             # this launch's: side stream, behind the launch
         k = sync()                                       # HIP events on the launch stream; also synchronises
@@ -138,7 +141,7 @@ def run_timed(env: capi.Env, policy, steps: int, repeats: int, exchange, barrier
         kms.append(float(k) if k is not None else float("nan"))
     if exchange.open:
         records = exchange.end()
-    return {"wall_s": walls, "kernel_ms": kms, "records": records}
+    return {"wall_s": walls, "kernel_ms": kms, "exchange_end_s": ends, "records": records}
 
 
 class Rendezvous:

@@ -16,6 +16,11 @@ What is mirrored (reference paths):
   * ``python -m ft_grandprix_amd.sim --cars template/cars/cars.json --track track --steps N``: the headless form of
     ``python -m ft_grandprix.drive`` (drive.py:69-115: roster + track in, physics loop out)
   * ``reset()`` = Mujoco.reload(): drivers re-instantiated, race state cleared, cars re-spawned -- custom.py:1089-1128
+  * the options that change a step (plain constructor arguments / attributes here):
+    ``detach_control`` (custom.py:952,1421-1423: drivers run, ``data.ctrl`` is not written), ``manual_control`` + ``watching`` +
+    ``manual_speed`` / ``manual_steering_angle`` (custom.py:954-957,1413-1416: the watched car takes the keyboard's controls, coasting
+    at 0.99 of its throttle when no key is held), ``always_invoke_driver`` (custom.py:956,1403: with manual control on, whether the
+    drivers are still called), ``rangefinder_tilt`` (custom.py:986,1387: FAKELIDAR mode only, see ``tilted_fan``)
 The physics / LiDAR / lap logic themselves run on the GPU behind ``capi.Env``.
 """
 from __future__ import annotations
@@ -69,6 +74,21 @@ def ordinal(n: int) -> str:
     return text + suffix
 
 
+def tilted_fan(n_rays: int, tilt: float) -> np.ndarray:
+    """The FAKELIDAR fan under the option ``rangefinder_tilt`` (custom.py:986,1387): the reference lays its scan angles out as
+    ``linspace(tilt + yaw + pi, yaw - pi, r, endpoint=False)`` -- the tilt moves the START of the sweep and not its end, so scan
+    i is turned by ``tilt * (1 - i / r)``: the rear ray by the whole tilt, the last one by tilt / r.  Those angles live in the
+    y-down pixel frame, where a positive turn is a clockwise one in the world; the rangefinders' own order (index 0 = rear,
+    counter-clockwise, include/ftgp.h) is kept, as SURVEY.md 8a-3 prescribes for this never-exercised branch.  Returns the
+    body-frame directions [n_rays, 2] (binary64) for ``FtgpConfig.fan_dirs``; tilt = 0 gives the default fan bit for bit."""
+    j = np.arange(n_rays, dtype=np.float64)
+    phi = np.array([math.radians(360.0 / n_rays * k - 90.0) for k in range(n_rays)])       # mushr.em.xml:112-117
+    if tilt == 0.0:
+        return np.stack([np.array([math.sin(p) for p in phi]), np.array([-math.cos(p) for p in phi])], axis=1)
+    turned = phi - tilt * (1.0 - j / n_rays)
+    return np.stack([np.sin(turned), -np.cos(turned)], axis=1)
+
+
 def resolve_driver_path(spec: str) -> Optional[str]:
     """Roster 'driver' string -> importable module path (custom.py:1097-1104)."""
     if spec.startswith("file://"):
@@ -114,11 +134,18 @@ class Simulator:
 
     def __init__(self, track: Track, cars: Sequence[dict], n_envs: int = 1, n_rays: int = 90, lap_target: int = 10,
                  lib: Optional[capi.CLib] = None, spawn_mode: int = 0, seed: int = 1234, device_id: int = 0,
-                 lidar_mode="rangefinder"):
+                 lidar_mode="rangefinder", detach_control: bool = False, manual_control: bool = False,
+                 always_invoke_driver: bool = True, rangefinder_tilt: float = 0.0):
         self.lib = lib if lib is not None else capi.load()
         self.cars = list(cars)
+        # options that change a step (custom.py:952-957,986); plain attributes: a caller may flip them between steps, as the GUI does
+        self.detach_control, self.manual_control, self.always_invoke_driver = detach_control, manual_control, always_invoke_driver
+        self.watching: Optional[int] = 0                             # custom.py:931: the car the manual controls go to
+        self.manual_speed, self.manual_steering_angle = 0.0, 0.0     # ModelAndView.speed / .steering_angle (custom.py:465-482): what the keys hold
+        self.rangefinder_tilt = float(rangefinder_tilt)
+        fan = tilted_fan(n_rays, self.rangefinder_tilt) if (lidar_mode == "fakelidar" and self.rangefinder_tilt != 0.0) else None
         self.env = capi.Env(self.lib, track, n_envs=n_envs, cars_per_env=len(self.cars), n_rays=n_rays,
-                            lap_target=lap_target, spawn_mode=spawn_mode, seed=seed, device_id=device_id, lidar_mode=lidar_mode)
+                            lap_target=lap_target, spawn_mode=spawn_mode, seed=seed, device_id=device_id, lidar_mode=lidar_mode, fan_dirs=fan)
         self.n_envs, self.cars_per_env, self.n_rays = n_envs, len(self.cars), n_rays
         self.timestep = self.env.dt
         self.steps = 0
@@ -177,16 +204,27 @@ class Simulator:
         snaps = self.snapshots() if any(vs.v2 for vs in self.vehicle_states) else None
         ctrl = np.zeros((self.env.n_cars, 2))
         mask = np.ones(self.env.n_cars, dtype=np.uint8)
+        current = None
         for vs in self.vehicle_states:
             args = [ranges[vs.id], snaps[vs.id]] if vs.v2 else [ranges[vs.id]]
-            try:
-                speed, steering_angle = vs.driver.process_lidar(*args)
-            except Exception as e:
-                print(f"Error in vehicle `{vs.label}`: `{e}`")
-                mask[vs.id] = 0
-                continue
+            speed, steering_angle = 0.0, 0.0                             # custom.py:1401
+            if self.always_invoke_driver or not self.manual_control:     # custom.py:1403
+                try:
+                    speed, steering_angle = vs.driver.process_lidar(*args)
+                except Exception as e:
+                    print(f"Error in vehicle `{vs.label}`: `{e}`")
+                    mask[vs.id] = 0                                      # `continue`: this car's ctrl stays what it was (custom.py:1409-1411)
+                    continue
+            if self.manual_control and self.watching == vs.id:           # custom.py:1413-1416
+                speed, steering_angle = self.manual_speed, self.manual_steering_angle
+                if current is None:
+                    current = self.env.ctrl()
+                if speed == 0.0 and current[vs.id, 0] > 0.0:
+                    speed = current[vs.id, 0] * 0.99
             vs.speed, vs.steering_angle = speed, steering_angle
             ctrl[vs.id] = (speed, steering_angle)
+        if self.detach_control:                                          # custom.py:1421-1423: nobody's data.ctrl is written
+            mask[:] = 0
         self.env.set_ctrl(ctrl, mask)
         self.env.step(1)
         self.steps += 1

@@ -53,7 +53,9 @@ extern "C" {
 #define FTGP_PATH_POINTS   100   /* ft_grandprix/curve.py:8 */
 #define FTGP_MAX_LAP_TIMES  32   /* lap times kept per car: a ring of the NEWEST 32 -- lap time number k (0-based, in the order VehicleState.times
                                     lists them, custom.py:124,1351-1363) sits in slot k % 32; the true count is kept beside it.  VehicleState.times
-                                    is unbounded; lap_target defaults to 10 (custom.py:961) */
+                                    is unbounded; lap_target defaults to 10 (custom.py:961).  A backward crossing pops the newest entry (custom.py:1355-1356):
+                                    while more than 32 lap times have been counted, the popped entry had overwritten the oldest one the list would
+                                    still show -- that slot then reads NaN (= no entry; skipped by the metrics record's min / max) until it is filled again */
 
 /* number of doubles / ints per car in the packed read-back rows */
 #define FTGP_SNAPSHOT_DOUBLES 10 /* laps, vel[3], yaw, pitch, roll, lap_completion, absolute_completion, time */
@@ -236,6 +238,11 @@ int ftgp_get_winners(FtgpEnv *env, int32_t *out);
 /* counts: int32[n_cars] = len(VehicleState.times), the TRUE count; times: double[n_cars][FTGP_MAX_LAP_TIMES] = the ring of the newest
  * 32 (lap time k in slot k % 32, see FTGP_MAX_LAP_TIMES); replaces VehicleState.times (custom.py:124,1351-1363). */
 int ftgp_get_lap_times(FtgpEnv *env, int32_t *counts, double *times);
+
+/* int64[n_cars][2] = (start, finish_step): the env step of the car's last counted line crossing (vehicle_state.start, custom.py:1362) and
+ * the env step at which `finished` was set (-1 while racing) with all 64 bits of self.steps; columns 6 and 9 of ftgp_get_progress hold the
+ * same two saturated at 2^31 - 1. */
+int ftgp_get_race_steps(FtgpEnv *env, int64_t *out);
 
 /* double[n_cars][2] current controls. */
 int ftgp_get_ctrl(FtgpEnv *env, double *out);

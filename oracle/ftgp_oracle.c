@@ -50,10 +50,11 @@ typedef struct Car {
     /* controls */
     double u_speed, u_steer;
     /* race state (custom.py:91-143) */
-    int32_t completion, laps, start, offset;
+    int32_t completion, laps, offset;
     int32_t good_start, finished, off_track, delta;
     int32_t n_times;
-    int32_t finish_step;     /* self.steps when `finished` was set (custom.py:1367-1370) */
+    int64_t start;           /* vehicle_state.start (custom.py:1362): 64 bits like self.steps */
+    int64_t finish_step;     /* self.steps when `finished` was set (custom.py:1367-1370) */
     double times[FTGP_MAX_LAP_TIMES];
     double dist2;            /* distance_from_track (squared, custom.py:1343) */
     /* fast.py:12 */
@@ -568,19 +569,24 @@ static void progress_car(OracleEnv *e, int ci)
         if (a->delta < 0) {
             a->laps -= 1;
             a->good_start = 0;
-            if (a->n_times != 0) a->n_times -= 1;
+            if (a->n_times != 0) {                     /* times.pop() */
+                /* beyond FTGP_MAX_LAP_TIMES counted laps the popped entry sits where the oldest entry the list would still show used to be:
+                 * that slot holds no entry now (NaN), see include/ftgp.h */
+                if (a->n_times > FTGP_MAX_LAP_TIMES) a->times[(a->n_times - 1) % FTGP_MAX_LAP_TIMES] = NAN;
+                a->n_times -= 1;
+            }
         } else if (a->delta > 0) {
             if (a->good_start) {
                 a->times[a->n_times % FTGP_MAX_LAP_TIMES] = lap_time;   /* times.append(lap_time); the newest FTGP_MAX_LAP_TIMES are kept */
                 a->n_times += 1;
-                a->start = (int32_t)steps;
+                a->start = steps;
             }
             a->laps += 1;
             a->good_start = 1;
         }
     }
     if (a->laps >= e->cfg.lap_target) {              /* custom.py:1367-1370: winners[id] = len(winners) + 1 the first time */
-        if (!a->finished) a->finish_step = steps > 0x7fffffffll ? 0x7fffffff : (int32_t)steps;   /* int32 row: saturates */
+        if (!a->finished) a->finish_step = steps;
         if (e->place[ci] == 0) e->place[ci] = ++e->n_winners[env];     /* kept the reference's way: a dict filled inside the per-car loop */
         a->finished = 1;
     }
@@ -906,9 +912,10 @@ int oracle_create(const FtgpConfig *cfg, OracleEnv **out)
         double phi = ((360.0 / (double)R) * (double)j - 90.0) * (M_PI / 180.0);
         e->ray_bxd[j] = cfg->fan_dirs ? cfg->fan_dirs[2 * j] : sin(phi);
         e->ray_byd[j] = cfg->fan_dirs ? cfg->fan_dirs[2 * j + 1] : -cos(phi);
-        /* the rangefinders' own fan is point-symmetric, and the table is so to the last bit: site j + R/2 = -(site j) */
-        if (!cfg->fan_dirs && R % 2 == 0 && j >= R / 2) { e->ray_bxd[j] = -e->ray_bxd[j - R / 2]; e->ray_byd[j] = -e->ray_byd[j - R / 2]; }
         e->ray_bx[j] = (float)e->ray_bxd[j]; e->ray_by[j] = (float)e->ray_byd[j];
+        /* the rangefinders' own fan is point-symmetric, and the BINARY32 table says so to the last bit: site j + R/2 = -(site j) (DESIGN.md
+         * section 4).  The binary64 fan (FAKELIDAR mode) stays libm's sin / cos of every phi_j: what include/ftgp.h documents for fan_dirs == NULL */
+        if (!cfg->fan_dirs && R % 2 == 0 && j >= R / 2) { e->ray_bx[j] = -e->ray_bx[j - R / 2]; e->ray_by[j] = -e->ray_by[j - R / 2]; }
     }
     for (int p = 0; p < NPATH; ++p) {
         /* custom.py:1240-1245 + 81-87 with pitch = roll = 0 */
@@ -1056,7 +1063,9 @@ int oracle_get_progress(OracleEnv *e, int32_t *out)
         const Car *a = &e->cars[i]; int32_t *o = out + (size_t)i * FTGP_PROGRESS_INTS;
         int lc = lap_completion(a);
         o[0] = a->laps; o[1] = a->completion; o[2] = lc; o[3] = a->laps * 100 + lc; o[4] = a->finished;
-        o[5] = a->off_track; o[6] = a->start; o[7] = a->good_start; o[8] = a->delta; o[9] = a->finished ? a->finish_step : -1;
+        const int64_t top = 0x7fffffffll;                 /* the row is int32: start and finish_step saturate (oracle_get_race_steps has all 64 bits) */
+        o[5] = a->off_track; o[6] = (int32_t)(a->start > top ? top : a->start); o[7] = a->good_start; o[8] = a->delta;
+        o[9] = a->finished ? (int32_t)(a->finish_step > top ? top : a->finish_step) : -1;
     }
     return 0;
 }
@@ -1102,6 +1111,12 @@ int oracle_get_distance_field(OracleEnv *e, double *out)
     return 0;
 }
 int oracle_get_field(OracleEnv *e, uint8_t *out) { memcpy(out, e->field, (size_t)e->cfg.track.width * e->cfg.track.height); return 0; }
+
+int oracle_get_race_steps(OracleEnv *e, int64_t *out)
+{
+    for (int i = 0; i < e->n_cars; ++i) { out[2 * i] = e->cars[i].start; out[2 * i + 1] = e->cars[i].finished ? e->cars[i].finish_step : -1; }
+    return 0;
+}
 
 int oracle_metrics_local(OracleEnv *e, double *out)
 {
@@ -1172,7 +1187,7 @@ int oracle_progress_trace(int offset, int lap_target, double dt, int n, const in
             a.delta = (((completion - a.completion + 50) % 100) + 100) % 100 - 50;
             if (abs(delta) > 90) {
                 double lap_time = (double)(s - a.start) * dt;
-                if (a.delta < 0) { a.laps -= 1; a.good_start = 0; if (a.n_times != 0) a.n_times -= 1; }
+                if (a.delta < 0) { a.laps -= 1; a.good_start = 0; if (a.n_times != 0) { if (a.n_times > FTGP_MAX_LAP_TIMES) a.times[(a.n_times - 1) % FTGP_MAX_LAP_TIMES] = NAN; a.n_times -= 1; } }
                 else if (a.delta > 0) {
                     if (a.good_start) { a.times[a.n_times % FTGP_MAX_LAP_TIMES] = lap_time; a.n_times += 1; a.start = s; }
                     a.laps += 1; a.good_start = 1;

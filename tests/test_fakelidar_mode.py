@@ -48,6 +48,9 @@ def check_g8(lib, name):
         got = step_from_poses(lib, t, g[f"{name}_xy"], g[f"{name}_quat"], R, g[f"fan_{R}"])
         np.testing.assert_array_equal(got, g[f"{name}_{R}_ranges"])
         assert (got > 0).all()
+        # fan_dirs = NULL: the fan include/ftgp.h documents -- (sin phi_j, -cos phi_j) in binary64 for every site -- is the fixture's fan,
+        # so the default-fan path (bench --lidar fakelidar, sim --lidar fakelidar) is pinned by the reference too
+        np.testing.assert_array_equal(step_from_poses(lib, t, g[f"{name}_xy"], g[f"{name}_quat"], R, None), g[f"{name}_{R}_ranges"])
 
 
 def preimage(target, scale, size):

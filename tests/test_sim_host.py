@@ -124,3 +124,77 @@ def test_lap_times_are_a_ring_of_the_newest_32(oracle):
     times = capi.lap_time_list(count, ring)
     assert len(times) == capi.MAX_LAP_TIMES and all(abs(t - per_lap * 0.004) < 1e-12 for t in times)
     assert capi.lap_time_list(3, ring) == [ring[0], ring[1], ring[2]]
+
+
+def _counting_driver(name, out):
+    import types
+
+    class D:
+        calls = 0
+
+        def process_lidar(self, ranges):
+            D.calls += 1
+            return out
+    m = types.ModuleType(name); m.Driver = D; sys.modules[name] = m
+    return D
+
+
+def test_detach_control_runs_the_drivers_and_writes_no_ctrl(oracle):
+    """Option "detach_control" (custom.py:952,1421-1423): process_lidar is still called, vehicle_state.speed / .steering_angle are
+    set, data.ctrl stays what it was."""
+    D = _counting_driver("ftgp_detached_driver", (2.0, 0.3))
+    sim = Simulator(load_track("small-circle"), [{"driver": "ftgp_detached_driver", "name": "a"}], n_rays=36, lib=oracle)
+    sim.drive(3)
+    np.testing.assert_array_equal(sim.env.ctrl()[0], [2.0, 0.3])
+    sim.env.set_ctrl(np.array([[0.5, -0.1]]))
+    sim.detach_control = True
+    before = D.calls
+    sim.drive(5)
+    assert D.calls == before + 5                                                         # drivers called ...
+    np.testing.assert_array_equal(sim.env.ctrl()[0], [0.5, -0.1])                        # ... ctrl unchanged
+    assert (sim.vehicle_states[0].speed, sim.vehicle_states[0].steering_angle) == (2.0, 0.3)
+    sim.close()
+
+
+def test_manual_control_overrides_the_watched_car_only(oracle):
+    """Options "manual_control" / "always_invoke_driver" (custom.py:954-957,1403,1413-1416): the watched car takes the keyboard's
+    controls -- coasting at 0.99 of its throttle when no key is held -- the others keep their drivers'; with always_invoke_driver
+    off the drivers are not called at all and the unwatched cars get (0, 0)."""
+    D = _counting_driver("ftgp_manual_driver", (1.5, 0.2))
+    roster = [{"driver": "ftgp_manual_driver", "name": "a"}, {"driver": "ftgp_manual_driver", "name": "b"}]
+    sim = Simulator(load_track("small-circle"), roster, n_rays=36, lib=oracle, manual_control=True)
+    sim.watching, sim.manual_speed, sim.manual_steering_angle = 1, 3.0, -0.4                # custom.py:958: manual_control_speed = 3
+    sim.step()
+    c = sim.env.ctrl()
+    np.testing.assert_array_equal(c[0], [1.5, 0.2]); np.testing.assert_array_equal(c[1], [3.0, -0.4])
+    sim.manual_speed = 0.0                                                               # key released: 0.99 of the current throttle
+    sim.step()
+    np.testing.assert_allclose(sim.env.ctrl()[1], [3.0 * 0.99, -0.4], rtol=0, atol=1e-15)
+    sim.always_invoke_driver = False
+    before = D.calls
+    sim.step()
+    assert D.calls == before
+    np.testing.assert_array_equal(sim.env.ctrl()[0], [0.0, 0.0])
+    sim.close()
+
+
+def test_rangefinder_tilt_turns_the_fakelidar_fan(oracle):
+    """Option "rangefinder_tilt" (custom.py:986,1387): linspace(tilt + yaw + pi, yaw - pi, r): scan i is turned by tilt * (1 - i / r).
+    tilt = 0 is the default fan bit for bit; a tilt of one ray spacing turns the rear ray onto its neighbour's direction."""
+    from ft_grandprix_amd.sim import tilted_fan
+    import math
+    R = 36
+    f0 = tilted_fan(R, 0.0)
+    want = np.array([[math.sin(math.radians(360.0 / R * j - 90.0)), -math.cos(math.radians(360.0 / R * j - 90.0))] for j in range(R)])
+    np.testing.assert_array_equal(f0, want)
+    step = 2 * math.pi / R
+    f1 = tilted_fan(R, step)
+    np.testing.assert_allclose(f1[0], want[-1], rtol=0, atol=1e-15)                      # the rear ray: turned by the whole tilt, clockwise in the world
+    np.testing.assert_allclose(f1[R // 2], [math.sin(math.radians(90.0) - step / 2), -math.cos(math.radians(90.0) - step / 2)], rtol=0, atol=1e-15)
+    t = load_track("small-circle")
+    a = Simulator(t, [{"driver": "ft_grandprix_amd.drivers.follow_gap", "name": "a"}], n_rays=R, lib=oracle, lidar_mode="fakelidar")
+    b = Simulator(t, [{"driver": "ft_grandprix_amd.drivers.follow_gap", "name": "a"}], n_rays=R, lib=oracle, lidar_mode="fakelidar", rangefinder_tilt=step)
+    a.step(); b.step(); a.step(); b.step()
+    ra, rb = a.env.lidar()[0], b.env.lidar()[0]
+    assert not np.array_equal(ra, rb) and abs(rb[0] - ra[-1]) < 0.05 * max(ra[-1], 1e-9) + 0.05   # b's rear ray looks where a's last ray looks
+    a.close(); b.close()

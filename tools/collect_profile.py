@@ -77,8 +77,10 @@ for tag, ctrs in (("a", ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_SALU"
 c = sq["counters"]; n = ENVS * CARS * STEPS
 sq["derived"] = {"valu_insts_per_car_step": c["SQ_INSTS_VALU"] / n, "salu_insts_per_car_step": c["SQ_INSTS_SALU"] / n,
                  "lds_insts_per_car_step": c["SQ_INSTS_LDS"] / n, "vmem_rd_insts_per_car_step": c["SQ_INSTS_VMEM_RD"] / n,
-                 "valu_issue_frac_of_2cycle_peak": c["SQ_INSTS_VALU"] * 2.0 / (1024 * c["GRBM_GUI_ACTIVE"] / 8.0),
-                 "valu_busy_frac": c["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024 * c["GRBM_GUI_ACTIVE"] / 8.0),
+                 # the vector pipe's occupancy lies between these two: every instruction priced at the cheapest (v_add_u32, 2.28 SIMD-cycles) / the
+                 # dearest common kind (v_cmp, 4.32) of tools/issue_calib.sh; SQ_ACTIVE_INST_VALU ticks once per instruction and is no cycle count
+                 "valu_pipe_occupancy_lower": c["SQ_INSTS_VALU"] * 2.28 / (1024 * c["GRBM_GUI_ACTIVE"] / 8.0),
+                 "valu_pipe_occupancy_upper": min(1.0, c["SQ_INSTS_VALU"] * 4.32 / (1024 * c["GRBM_GUI_ACTIVE"] / 8.0)),
                  "wait_any_frac_of_wave_cycles": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], "wait_inst_frac_of_wave_cycles": c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"],
                  "shader_clock_ghz": c["GRBM_GUI_ACTIVE"] / 8.0 / (sq["kernel_ms"] * 1e6)}
 json.dump(sq, open(f"{OUT}/sq_{TAG}.json", "w"), indent=1)
@@ -97,7 +99,7 @@ tr["algorithmic_bytes_per_env_step"] = CARS * (4 * RAYS + 832)
 json.dump(tr, open(f"{OUT}/traffic_{TAG}.json", "w"), indent=1)
 
 # 3. the bench line reads these two files: give it the ones of this very visit (same sources, so nothing is "stale")
-PROFILES = "profiles/round4"
+PROFILES = "profiles/round5"
 os.makedirs(PROFILES, exist_ok=True)
 for name in (f"sq_{TAG}.json", f"traffic_{TAG}.json"):
     shutil.copy(f"{OUT}/{name}", f"{PROFILES}/{name}")
