@@ -27,7 +27,7 @@ struct alignas(16) CarCore {
 struct alignas(16) CarState : CarCore {
     double times[FTGP_MAX_LAP_TIMES];
 };
-static_assert(sizeof(CarCore) == 192, "CarCore layout");
+static_assert(sizeof(CarCore) == 192 && offsetof(CarCore, finish_step) == offsetof(CarCore, start) + 8, "CarCore layout (progress_update reaches finish_step through &start)");
 static_assert(sizeof(CarState) == 192 + 8 * FTGP_MAX_LAP_TIMES, "CarState layout");
 static_assert((FTGP_MAX_LAP_TIMES & (FTGP_MAX_LAP_TIMES - 1)) == 0, "the lap-time ring is indexed with a mask");
 

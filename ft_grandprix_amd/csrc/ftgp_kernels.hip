@@ -577,9 +577,11 @@ __global__ void ftgp_selftest_rcp_kernel(unsigned long long* __restrict__ mismat
 // =============================================================================================
 // K3: lap progress (custom.py:1340-1372)
 // =============================================================================================
-struct Race { int32_t completion, laps, offset, good_start, finished, off_track, delta, n_times; int64_t start, finish_step; double dist2; };
+// (start and finish_step -- 64 bits each, touched on line crossings only -- stay in the car's record and are reached through `steps64`:
+// carried in registers they would push the K1 + K3 wave over the kernel's 64-register budget)
+struct Race { int32_t completion, laps, offset, good_start, finished, off_track, delta, n_times; double dist2; };
 
-__device__ __forceinline__ void progress_update(const DeviceParams& P, Race& s, int64_t steps, int closest, double best, double* __restrict__ times)
+__device__ __forceinline__ void progress_update(const DeviceParams& P, Race& s, int64_t steps, int closest, double best, double* __restrict__ times, int64_t* steps64 /* &start, &finish_step */)
 {
     s.dist2 = best;                                       // custom.py:1343 (squared)
     s.off_track = best > 1.0;                             // custom.py:1344
@@ -588,28 +590,31 @@ __device__ __forceinline__ void progress_update(const DeviceParams& P, Race& s, 
     const int delta = completion - s.completion;
     s.delta = (((completion - s.completion + 50) % 100) + 100) % 100 - 50;
     if (abs(delta) > 90) {
-        const double lap_time = (double)(steps - s.start) * P.dt;
+        // one store site for the ring (an appended lap time, or the mark of an emptied slot): two would not fit the K1 + K3 wave's registers
+        double val = (double)(steps - steps64[0]) * P.dt;      // lap_time
+        int slot = -1;
         if (s.delta < 0) {                                // backwards across the line, custom.py:1352-1356
             s.laps -= 1;
             s.good_start = 0;
             if (s.n_times != 0) {                             // times.pop()
                 // the ring keeps the newest FTGP_MAX_LAP_TIMES: beyond that the popped entry sits in the slot of the oldest one the list would
                 // still show (it was overwritten when the popped lap was appended) -- that slot is marked empty (NaN: skipped by every reader)
-                if (s.n_times > FTGP_MAX_LAP_TIMES) times[(s.n_times - 1) & (FTGP_MAX_LAP_TIMES - 1)] = __longlong_as_double(0x7ff8000000000000ll);
+                if (s.n_times > FTGP_MAX_LAP_TIMES) { slot = s.n_times - 1; val = val * __builtin_nan(""); }
                 s.n_times -= 1;
             }
         } else if (s.delta > 0) {                         // custom.py:1357-1366
             if (s.good_start) {
-                times[s.n_times & (FTGP_MAX_LAP_TIMES - 1)] = lap_time;      // times.append(lap_time): a ring of the newest FTGP_MAX_LAP_TIMES
+                slot = s.n_times;                             // times.append(lap_time): a ring of the newest FTGP_MAX_LAP_TIMES
                 s.n_times += 1;
-                s.start = steps;
+                steps64[0] = steps;
             }
             s.laps += 1;
             s.good_start = 1;
         }
+        if (slot >= 0) times[slot & (FTGP_MAX_LAP_TIMES - 1)] = val;
     }
     if (s.laps >= P.lap_target) {                         // custom.py:1367-1370; the step of the first time orders the winners (custom.py:1368-1369)
-        if (!s.finished) s.finish_step = steps;
+        if (!s.finished) steps64[1] = steps;
         s.finished = 1;
     }
     s.completion = completion;
@@ -617,15 +622,15 @@ __device__ __forceinline__ void progress_update(const DeviceParams& P, Race& s, 
 
 __device__ __forceinline__ void race_load(Race& r, const CarCore* st)
 {
-    r.completion = st->completion; r.laps = st->laps; r.start = st->start; r.offset = st->offset;
+    r.completion = st->completion; r.laps = st->laps; r.offset = st->offset;
     r.good_start = st->good_start; r.finished = st->finished; r.off_track = st->off_track; r.delta = st->delta;
-    r.n_times = st->n_times; r.finish_step = st->finish_step; r.dist2 = st->dist2;
+    r.n_times = st->n_times; r.dist2 = st->dist2;
 }
 __device__ __forceinline__ void race_store(const Race& r, CarCore* st)
 {
-    st->completion = r.completion; st->laps = r.laps; st->start = r.start;
+    st->completion = r.completion; st->laps = r.laps;
     st->good_start = r.good_start; st->finished = r.finished; st->off_track = r.off_track; st->delta = r.delta;
-    st->n_times = r.n_times; st->finish_step = r.finish_step; st->dist2 = r.dist2;
+    st->n_times = r.n_times; st->dist2 = r.dist2;
 }
 
 // =============================================================================================
@@ -1009,7 +1014,7 @@ __device__ __forceinline__ void dynamics_lanes(const DeviceParams& P, const Lds&
     quad_argmin_step<0x4E>(best, idx);
     if (on && r == 0) {
         Race rc; race_load(rc, st);
-        progress_update(P, rc, L.steps[c], idx, best, P.cars[ci0 + c].times);
+        progress_update(P, rc, L.steps[c], idx, best, P.cars[ci0 + c].times, &st->start);
         race_store(rc, st);
     }
     wave_lds_sync();
@@ -1617,7 +1622,7 @@ __device__ __forceinline__ void progress_lane(const DeviceParams& P, CarCore& s,
         if (i == 0 || d < best) { best = d; closest = i; }
     }
     Race r; race_load(r, &s);
-    progress_update(P, r, steps, closest, best, times);
+    progress_update(P, r, steps, closest, best, times, &s.start);
     race_store(r, &s);
 }
 
