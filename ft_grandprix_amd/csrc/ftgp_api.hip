@@ -214,7 +214,7 @@ int lds_layout(DeviceParams& P, int cpb, int wpb)
     P.off_scan = o;   o += 2 * cpb * P.win_floats * (int)sizeof(float);   // double-buffered by step parity
     P.off_list = o;   o += std::min(cpb, wpb) * FTGP_WAVE * (int)sizeof(int);                 // driver scratch: wave c runs the driver of car c
     P.off_pool = o;   o += 32;
-    P.off_k1 = o;     o += cpb * (FTGP_FORCE_TERMS * 24 + 4 * 8 + 104);                         // K1 staging: force terms | new wheel spins | new state
+    P.off_k1 = o;     o += cpb * (FTGP_FORCE_TERMS * 24 + 4 * 8 + 104 + (P.cars_per_env > 1 ? FTGP_PAIR_STRIDE * 24 : 0));   // K1 staging: force terms | new wheel spins | new state [| contact sums per env-mate]
     P.mmask_stride = pad16((size_t)2 * (size_t)((P.n_rays + FTGP_WAVE - 1) / FTGP_WAVE + 2));      // two groups per task, never more tasks than groups of 64 rays + 2
     P.off_mmask = o;  if (P.cars_per_env > 1) o += 2 * cpb * P.mmask_stride;              // env-mate visibility masks, double-buffered by step parity
     P.stage_cover = pad16(sizeof(float) * (size_t)(P.cover_kmax + 1));
@@ -532,9 +532,14 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
         int wpb = 16;
         if (const char* sv = getenv("FTGP_WAVES_PER_BLOCK")) { const int c = atoi(sv); if (c >= 1 && c <= 16) wpb = c; }
         int want = (FTGP_MAX_CARS_PER_BLOCK / unit) * unit;
-        // small batches: fewer cars per workgroup so that every CU gets two workgroups (256 CUs)
+        // small batches: fewer cars per workgroup so that every CU gets work.  Up to four envs per CU a batch runs best as ONE workgroup per CU
+        // (its step is the driver -> dynamics latency chain plus one sweep task per wave: a second workgroup on the CU only competes for issue
+        // slots -- 1024 envs: 9.1 us per step with 256 workgroups of 4, 9.8 with 512 of 2; 512 envs: 8.8 / 9.0); larger batches take two
+        // workgroups per CU (1536 envs: 10.7 us with 512 workgroups of 3, 13.9 with 256 of 6) -- profiles/round5/config2_shapes.log
         const int n_units = P.n_cars / unit;
-        const int spread = std::max(1, n_units / 512) * unit;
+        const int n_cu = P.n_cu > 0 ? P.n_cu : 256;
+        const int per_cu = (n_units + n_cu - 1) / n_cu;
+        const int spread = (per_cu <= 4 ? std::max(1, per_cu) : std::max(1, n_units / (2 * n_cu))) * unit;
         int cpb = std::min(want, spread);
         if (const char* sv = getenv("FTGP_CARS_PER_BLOCK")) { const int c = atoi(sv); if (c >= unit && c <= FTGP_MAX_CARS_PER_BLOCK) cpb = (c / unit) * unit; }
         int lds_cap = 80 * 1024;
@@ -1161,6 +1166,14 @@ int ftgp_debug_stamps(unsigned long long* out)
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ftgp_stamps), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
     unsigned long long z[16] = { 0 };
     return hipMemcpyToSymbol(HIP_SYMBOL(ftgp_stamps), z, sizeof z) == hipSuccess ? 0 : -1;
+}
+#endif
+#if defined(FTGP_DIAG) && defined(FTGP_STAMPS)
+int ftgp_debug_substamps(unsigned long long* out)          // read and clear
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ftgp_substamps), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
+    unsigned long long z[32] = { 0 };
+    return hipMemcpyToSymbol(HIP_SYMBOL(ftgp_substamps), z, sizeof z) == hipSuccess ? 0 : -1;
 }
 #endif
 #if defined(FTGP_DIAG) && defined(FTGP_WG_TIMES)

@@ -49,6 +49,7 @@ struct Lds {
     Force* terms;             // [cars_per_block][FTGP_FORCE_TERMS] K1 staging: force terms in the order they are summed
     double* wnew;             // [cars_per_block][4] K1 staging: new wheel spins
     Dyn* next;                // [cars_per_block] K1 staging: new dynamic state before the commit
+    Force* mates;             // [cars_per_block][FTGP_PAIR_STRIDE] K1 staging, multi-car envs: the contact forces with each env-mate, summed (car_contact_mate)
     const float* cover;       // [cover_kmax + 1] cover-count thresholds of the launch's driver (see cover_count)
     unsigned char* mmask;     // [2][cars_per_block][mmask_stride] multi-car envs: which env-mates each ray group of a car can see (mate_masks)
 };
@@ -121,6 +122,7 @@ __device__ __forceinline__ Lds lds_view(const LdsOffsets& o, unsigned char* lds)
     L.terms = reinterpret_cast<Force*>(k1);
     L.wnew = reinterpret_cast<double*>(k1 + o.cpb * (int)(FTGP_FORCE_TERMS * sizeof(Force)));
     L.next = reinterpret_cast<Dyn*>(k1 + o.cpb * (int)(FTGP_FORCE_TERMS * sizeof(Force) + 4 * sizeof(double)));
+    L.mates = reinterpret_cast<Force*>(k1 + o.cpb * (int)(FTGP_FORCE_TERMS * sizeof(Force) + 4 * sizeof(double) + sizeof(Dyn)));
     L.cover = reinterpret_cast<const float*>(lds + opaque(o.cover));
     L.mmask = lds + opaque(o.mmask);
     return L;
@@ -743,46 +745,45 @@ __device__ __forceinline__ Force wall_term(const DeviceParams& P, const FtgpVehi
     return t;
 }
 
-// Circles of this car against the circles of the other cars of the env (penalty spring/damper, pre-step states).  Runs on one
-// lane per car between two register-hungry blocks: the loops stay rolled and every operand is re-read from LDS where it is
-// used, so that the only values carried around the loops are the running force and a few indices.
-__device__ __forceinline__ void car_contact(const DeviceParams& P, const FtgpVehicle& v, const CarCore* me, const CarCore* env_cars, int my_slot, Force& f)
+// Circles of this car against the circles of ONE other car of the env (penalty spring/damper, pre-step states): the sum of the nine
+// circle pairs' forces, from +0, in the order i, j -- the specification adds the contacts with each env-mate up on their own and lets the
+// mates' sums join the car's force in the order of the mates (round 5: that is what lets a car's four lanes take a mate each; rounds 1-4
+// ran one sum over k, i, j on one lane, 27 dependent rounds of this loop body on the step's critical path).  The loop stays rolled and every
+// operand is re-read from LDS where it is used, so that the only values carried around it are the running sum and a few indices.
+__device__ __forceinline__ Force car_contact_mate(const FtgpVehicle& v, const CarCore* me, const CarCore* b)
 {
+    Force f = { 0.0, 0.0, 0.0 };
     #pragma unroll 1
-    for (int k = 0; k < P.cars_per_env; ++k) {
-        if (k == my_slot || env_cars[k].finished) continue;
-        const CarCore* b = env_cars + k;
-        #pragma unroll 1
-        for (int ij = 0; ij < 9; ++ij) {
-            FTGP_FORGET_REGISTERS();
-            const int i = ij / 3, j = ij - 3 * i;
-            const double r2 = 2.0 * v.contact_radius;
-            double rxw, ryw, sxw, syw, ex, ey;
-            {
-                const double qw = me->qw, qz = me->qz;
-                const double ch = 1.0 - 2.0 * (qz * qz), sh = 2.0 * (qw * qz);
-                rxw = ch * v.contact_x[i]; ryw = sh * v.contact_x[i];
-                const double bqw = b->qw, bqz = b->qz;
-                const double cb = 1.0 - 2.0 * (bqz * bqz), sb = 2.0 * (bqw * bqz);
-                sxw = cb * v.contact_x[j]; syw = sb * v.contact_x[j];
-                const double px = me->x + rxw, py = me->y + ryw;
-                const double qx = b->x + sxw, qy = b->y + syw;
-                ex = px - qx; ey = py - qy;
-            }
-            const double d2 = ex * ex + ey * ey;
-            if (d2 >= r2 * r2 || d2 <= 0.0) continue;
-            const double d = sqrt(d2);
-            const double nxv = ex / d, nyv = ey / d;
-            const double swz = me->wz, bwz = b->wz;
-            const double vax = me->vx - swz * ryw, vay = me->vy + swz * rxw;
-            const double vbx = b->vx - bwz * syw, vby = b->vy + bwz * sxw;
-            const double vn = (vax - vbx) * nxv + (vay - vby) * nyv;
-            const double mag = v.contact_stiffness * (r2 - d) - v.contact_damping * vn;
-            if (mag <= 0.0) continue;
-            const double fx = mag * nxv, fy = mag * nyv;
-            f.fx += fx; f.fy += fy; f.tz += rxw * fy - ryw * fx;
+    for (int ij = 0; ij < 9; ++ij) {
+        FTGP_FORGET_REGISTERS();
+        const int i = ij / 3, j = ij - 3 * i;
+        const double r2 = 2.0 * v.contact_radius;
+        double rxw, ryw, sxw, syw, ex, ey;
+        {
+            const double qw = me->qw, qz = me->qz;
+            const double ch = 1.0 - 2.0 * (qz * qz), sh = 2.0 * (qw * qz);
+            rxw = ch * v.contact_x[i]; ryw = sh * v.contact_x[i];
+            const double bqw = b->qw, bqz = b->qz;
+            const double cb = 1.0 - 2.0 * (bqz * bqz), sb = 2.0 * (bqw * bqz);
+            sxw = cb * v.contact_x[j]; syw = sb * v.contact_x[j];
+            const double px = me->x + rxw, py = me->y + ryw;
+            const double qx = b->x + sxw, qy = b->y + syw;
+            ex = px - qx; ey = py - qy;
         }
+        const double d2 = ex * ex + ey * ey;
+        if (d2 >= r2 * r2 || d2 <= 0.0) continue;
+        const double d = sqrt(d2);
+        const double nxv = ex / d, nyv = ey / d;
+        const double swz = me->wz, bwz = b->wz;
+        const double vax = me->vx - swz * ryw, vay = me->vy + swz * rxw;
+        const double vbx = b->vx - bwz * syw, vby = b->vy + bwz * sxw;
+        const double vn = (vax - vbx) * nxv + (vay - vby) * nyv;
+        const double mag = v.contact_stiffness * (r2 - d) - v.contact_damping * vn;
+        if (mag <= 0.0) continue;
+        const double fx = mag * nxv, fy = mag * nyv;
+        f.fx += fx; f.fy += fy; f.tz += rxw * fy - ryw * fx;
     }
+    return f;
 }
 
 // LiDAR frame of a car at its current pose (lidar_car() of the oracle: centre, heading, binary32 pixel coordinates).
@@ -894,6 +895,7 @@ __device__ __forceinline__ void dynamics_lanes(const DeviceParams& P, const Lds&
     Force* terms = L.terms + (on ? c : 0) * FTGP_FORCE_TERMS;
     const FtgpVehicle& v = L.veh->v;
     const bool finished = st->finished != 0;
+    SUBSTAMP_BEGIN();
     {   // ---- wheel r
         const double qw = st->qw, qz = st->qz;
         const double ch = 1.0 - 2.0 * (qz * qz), sh = 2.0 * (qw * qz);
@@ -945,6 +947,7 @@ __device__ __forceinline__ void dynamics_lanes(const DeviceParams& P, const Lds&
         if (on) { terms[r] = t; L.wnew[(on ? c : 0) * 4 + r] = rolling ? wn : wi; }
     }
     FTGP_FORGET_REGISTERS();
+    SUBSTAMP(0);
     {   // ---- wall-contact circle r and wheel softener r (a shadowed car collides with nothing, custom.py:1452-1457)
         Force t = { 0.0, 0.0, 0.0 };
         if (on && !finished && r < 3) t = wall_term(P, v, st, r, false);
@@ -955,13 +958,28 @@ __device__ __forceinline__ void dynamics_lanes(const DeviceParams& P, const Lds&
         if (on) terms[7 + r] = u;
     }
     FTGP_FORGET_REGISTERS();
+    SUBSTAMP(1);
+    if (MULTI) {                     // ---- car-car contacts: lane r takes env-mates r and r + 4 (a shadowed car collides with nothing, custom.py:1452-1457)
+        #pragma unroll 1
+        for (int k = r; k < sgpr(P.cars_per_env); k += 4) {
+            Force t = { 0.0, 0.0, 0.0 };
+            const CarCore* b = st + (k - c % P.cars_per_env);          // env-mate k of this car's env (cars of an env are neighbours in the workgroup)
+            if (on && !finished && b != st && !b->finished) t = car_contact_mate(v, st, b);
+            if (on) L.mates[c * FTGP_PAIR_STRIDE + k] = t;
+        }
+        FTGP_FORGET_REGISTERS();
+    }
     wave_lds_sync();                 // every lane has read the pre-step states; the force terms are staged
+    SUBSTAMP(2);
     if (on && r == 0) {
         Force f = { 0.0, 0.0, 0.0 };
         #pragma unroll 1
         for (int k = 0; k < FTGP_FORCE_TERMS; ++k) { const Force t = terms[k]; f.fx += t.fx; f.fy += t.fy; f.tz += t.tz; }
         const double qw = st->qw, qz = st->qz;
-        if (MULTI && !finished) car_contact(P, v, st, L.cars + (c - c % P.cars_per_env), c % P.cars_per_env, f);
+        if (MULTI) {                 // the env-mates' contact sums, in the order of the mates (zeros where nothing touches)
+            #pragma unroll 1
+            for (int k = 0; k < P.cars_per_env; ++k) { const Force t = L.mates[c * FTGP_PAIR_STRIDE + k]; f.fx += t.fx; f.fy += t.fy; f.tz += t.tz; }
+        }
         const double dt = P.dt;
         Dyn o;
         o.vx = st->vx + dt * (f.fx / v.mass);
@@ -985,6 +1003,7 @@ __device__ __forceinline__ void dynamics_lanes(const DeviceParams& P, const Lds&
         L.next[c] = o;               // committed below, after every car of the workgroup has read its neighbours' pre-step states
     }
     wave_lds_sync();
+    SUBSTAMP(3);
     {   // commit: the 13 doubles of the new dynamic state, spread over the car's four lanes
         if (on) {
             const double* src = reinterpret_cast<const double*>(L.next + c);
@@ -994,6 +1013,7 @@ __device__ __forceinline__ void dynamics_lanes(const DeviceParams& P, const Lds&
         }
     }
     wave_lds_sync();
+    SUBSTAMP(4);
     // ---- K3: distances = ((path - xpos)**2).sum(1); closest = distances.argmin() (first minimum), then the race-state update
     const double x = st->x, y = st->y;
     int idx = r * (FTGP_PATH_POINTS / 4);
@@ -1012,17 +1032,20 @@ __device__ __forceinline__ void dynamics_lanes(const DeviceParams& P, const Lds&
     // The lower index wins ties; a NaN never wins (the oracle's `d < best` is false for it too)
     quad_argmin_step<0xB1>(best, idx);
     quad_argmin_step<0x4E>(best, idx);
+    SUBSTAMP(5);
     if (on && r == 0) {
         Race rc; race_load(rc, st);
         progress_update(P, rc, L.steps[c], idx, best, P.cars[ci0 + c].times, &st->start);
         race_store(rc, st);
     }
     wave_lds_sync();
+    SUBSTAMP(6);
     // the LiDAR frames of the next step (its sweep starts after the workgroup barrier that ends this step)
     bool safe = true;
     if (on && r == 0) safe = frame_write(P, v, st, next_frames + c, c);
     const bool any_unsafe = __any(!safe);
     if (lane == 0) *unsafe_next = any_unsafe;
+    SUBSTAMP(7);
     if (MULTI) {                     // env-mate records of the new frames: lane r of a car writes mates r and r + 4
         wave_lds_sync();
         const float cull = L.veh->cull_radius, r0f = (float)v.lidar_ring_radius;
@@ -1122,6 +1145,7 @@ __device__ __forceinline__ void policy_disparity(const DriverShape& D, float* __
     // (the nearest one): rounding is monotone, so |fl(cur - prev)| > T implies the exact difference is > 0.6 and < T implies it
     // is not; only a difference that rounds to exactly T needs the binary64 comparison (NaNs fail every test, as there).
     const int K = (m + FTGP_WAVE - 1) / FTGP_WAVE;
+    SUBSTAMP_BEGIN();
     uint64_t mymask = 0;             // bit k: sample 64 k + lane is a disparity (needed again only beyond 64 disparities)
     int total = 0;                   // wave-uniform
     {
@@ -1151,6 +1175,7 @@ __device__ __forceinline__ void policy_disparity(const DriverShape& D, float* __
             }
         }
     }
+    SUBSTAMP(8);
     for (int c0 = 0; c0 < total; c0 += FTGP_WAVE) {
         if (c0 > 0) {                // disparities c0 .. c0 + 63 of more than 64: their indices again, from the kept flags
             int run = 0;
@@ -1193,6 +1218,7 @@ __device__ __forceinline__ void policy_disparity(const DriverShape& D, float* __
         }
     }
     wave_lds_sync();
+    SUBSTAMP(9);
     // argmax, first maximum (nidc.py:127) = what the sequential loop "x > best" finds: every lane scans its own samples (l, 64 + l,
     // ...) in index order and remembers the GROUP of its best one (a wave-uniform number: no index arithmetic per sample); then
     // the wave's maximum, and the lowest index among the lanes that hold it.  Sample 0 is the running maximum to begin with,
@@ -1222,6 +1248,7 @@ __device__ __forceinline__ void policy_disparity(const DriverShape& D, float* __
         const float b0 = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(bv)));
         if (b0 != b0) bi = 0;                                       // sample 0 is a NaN: nothing is greater
     }
+    SUBSTAMP(10);
     double ang = ((double)bi - ((double)m / 2)) * rpp;              // nidc.py:112
     const double lim = 90.0 * (M_PI / 180.0);
     if (ang < -lim) ang = -lim;
@@ -1237,6 +1264,7 @@ __device__ __forceinline__ void policy_disparity(const DriverShape& D, float* __
         else { const double sp = 0.5 * 5 * (1 - fabs(ang) / M_PI); speed = sp < 2.0 ? sp : 2.0; }
     }
     if (lane_id() == 0) { st->u_speed = speed; st->u_steer = ang; st->last_steer = last; }
+    SUBSTAMP(11);
 }
 
 // evaluates the driver of car ci and stores the controls into its state record

@@ -672,6 +672,9 @@ static void car_contact(const OracleEnv *e, int ci, double ch, double sh, Force 
         const Car *b = &e->cars[other];
         if (b->finished) continue;
         double cb = 1.0 - 2.0 * (b->qz * b->qz), sb = 2.0 * (b->qw * b->qz);
+        /* the contacts with one env-mate are added up on their own (from +0, in the order i, j) and the mates' sums join the car's force in
+         * the order k (round 5; rounds 1-4: one running sum over k, i, j -- the same bits unless two contacts act on a car at once) */
+        Force pk = { 0.0, 0.0, 0.0 };
         for (int i = 0; i < 3; ++i) {
             double rxw = ch * v->contact_x[i], ryw = sh * v->contact_x[i];
             double px = a->x + rxw, py = a->y + ryw;
@@ -689,9 +692,10 @@ static void car_contact(const OracleEnv *e, int ci, double ch, double sh, Force 
                 double mag = v->contact_stiffness * (r2 - d) - v->contact_damping * vn;
                 if (mag <= 0.0) continue;
                 double fx = mag * nxv, fy = mag * nyv;
-                f->fx += fx; f->fy += fy; f->tz += rxw * fy - ryw * fx;
+                pk.fx += fx; pk.fy += fy; pk.tz += rxw * fy - ryw * fx;
             }
         }
+        f->fx += pk.fx; f->fy += pk.fy; f->tz += pk.tz;
     }
 }
 

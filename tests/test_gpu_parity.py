@@ -477,13 +477,18 @@ def test_lap_time_ring_pop_beyond_the_ring_on_gpu(product):
     NaN, not the popped time -- against a Python list, and the 64-bit race steps (ftgp_get_race_steps) beside the int32 row."""
     from tests.test_oracle_golden import check_laps_with_a_pop
     check_laps_with_a_pop(product)
-    t = load_track("circle")
-    with capi.Env(product, t, n_envs=3, cars_per_env=2, n_rays=36, lap_target=1, spawn_mode=1, seed=5) as g:
-        g.rollout("nidc", 9000)
+    t = load_track("track")
+    with capi.Env(product, t, n_envs=1, n_rays=8, lap_target=2) as g:        # three laps by teleport, five steps each (laps_by_teleport)
+        pose = g.pose(); pose[:, 7:] = 0.0
+        for k in range(15):
+            pose[0, 0:2] = t.path[(10 + (25, 50, 75, 99, 0)[k % 5]) % 100]
+            g.set_pose(pose); g.step(1)
         p, rs = g.progress(), g.race_steps()
-        assert p[:, 4].any()                                                    # somebody finished
-        np.testing.assert_array_equal(rs[:, 0], p[:, 6]); np.testing.assert_array_equal(rs[:, 1], p[:, 9])      # far below 2^31: the row is exact
-        assert ((rs[:, 1] == -1) == (p[:, 4] == 0)).all()
+        assert p[0, 0] == 3 and p[0, 4] == 1
+        assert rs[0, 1] == 10 == p[0, 9]                 # `finished` was set when the second lap was counted: step 10
+        assert rs[0, 0] == 15 == p[0, 6]                 # vehicle_state.start: the last counted crossing
+    with capi.Env(product, t, n_envs=2, n_rays=8) as g:
+        np.testing.assert_array_equal(g.race_steps(), [[0, -1], [0, -1]])
 
 
 def test_launch_with_recorded_events_gives_the_same_results(product):

@@ -10,6 +10,8 @@ if os.environ.get("QUICK_ROSTER"):         # + template/cars/cars.json (nidc, fa
     cases = cases + (("track", "roster", 4096, 3, 100),)
 if os.environ.get("QUICK_CASES"):          # e.g. QUICK_CASES=0,2: only those rows
     cases = tuple(cases[int(i)] for i in os.environ["QUICK_CASES"].split(","))
+if os.environ.get("QUICK_ENVS"):           # another batch size for the selected rows
+    cases = tuple((n, p, int(os.environ["QUICK_ENVS"]), c, s) for n, p, _, c, s in cases)
 for path in libs:
     lib = capi.CLib(path, "ftgp_")
     out = []
