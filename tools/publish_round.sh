@@ -3,7 +3,7 @@
 # tools/soak.py) from gpurun_out/ into profiles/roundN.  tools/evidence.py refuses every file that was measured on other kernel sources
 # than the tree's.   publish_round.sh [profiles/round4]
 cd "$(dirname "$0")/.."
-dst=${1:-profiles/round4}
+dst=${1:-profiles/round5}
 P=gpurun_out/profile
 python3 tools/evidence.py publish "$dst" \
   $P/bench.json $P/bench_driver_shape.json $P/bench_config4_multi.json $P/bench_config1_circle.json \
