@@ -18,9 +18,14 @@ for line in open("gpurun_out/issue_by_type.log"):
 cyc = c["GRBM_GUI_ACTIVE"] / 8                      # shader cycles of the launch (8 XCDs report)
 simds = 1024
 print(f"shader cycles {cyc:.4g}; SIMD-cycles {cyc * simds:.4g}")
+# SQ_ACTIVE_INST_* tick once per instruction of the type (twice for a transcendental): instruction counts, NOT cycles (tools/issue_calib.sh,
+# profiles/round5/issue_calib.log) -- so they are printed per SIMD-cycle; what an instruction costs is in the calibration
 for k in ("ANY", "VALU", "SCA", "LDS", "VMEM", "FLAT", "MISC"):
     v = c.get("SQ_ACTIVE_INST_" + k)
-    if v is not None: print(f"SQ_ACTIVE_INST_{k:5s} x 4 / SIMD-cycles = {v * 4 / (cyc * simds):.3f}")
+    if v is not None: print(f"SQ_ACTIVE_INST_{k:5s} per SIMD-cycle = {v / (cyc * simds):.3f}")
+if "SQ_INSTS_VALU" in c:
+    print(f"vector pipe occupancy between {c['SQ_INSTS_VALU'] * 2.28 / (cyc * simds):.2f} (every vector instruction at v_add_u32's 2.28 SIMD-cycles) and "
+          f"{min(1.0, c['SQ_INSTS_VALU'] * 4.32 / (cyc * simds)):.2f} (at v_cmp's 4.32, capped at 1)")
 if "SQ_THREAD_CYCLES_VALU" in c and "SQ_ACTIVE_INST_VALU" in c:
     print(f"lanes enabled per vector instruction: SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU = {c['SQ_THREAD_CYCLES_VALU'] / c['SQ_ACTIVE_INST_VALU']:.1f} of 64")
 n = 4096 * 500
