@@ -235,7 +235,8 @@ __device__ __forceinline__ void sweep_priority(bool second_half)
 // instruction (profiles/round4/salu_cost.log) -- and the compiler's loop spends 13 scalar-side instructions per iteration on mask
 // bookkeeping.  Here a lane leaves the loop by dropping out of exec (v_cmpx on "the cell's entry is a box", i.e. kx != 0), so the
 // body needs no live mask, finished rays hold their cell and crossing time for free (and burn no vector lanes), and the loop
-// closes with one branch on exec: 18 vector + 3 scalar-side instructions per iteration, + the near-boundary path.
+// closes with one branch on exec: 21 vector (the look-up's six included; rounds 1-4: 23) + 3 scalar-side instructions per iteration, + the
+// near-boundary path.  Priced with tools/issue_calib.sh an iteration costs a SIMD about 85 cycles: two thirds of it selects, compares and conversions.
 // In: exec = the lanes that hold a ray; mx, my = cells travelled (0 at the origin), s = crossing time into the cell (0 at the origin).
 // Out: w = entry of the terminal cell (0 = wall, FTGP_FIELD_OUT = ring), s = crossing time into it, exec as on entry.
 // The arithmetic is ftgp_ray_step / ftgp_ray_fix / ftgp_ray_commit of ftgp_march.h, instruction for instruction: a crossing time is

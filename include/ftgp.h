@@ -146,7 +146,10 @@ typedef struct FtgpConfig {
     double map_size;                /* FAKELIDAR: world size of the map, 20 * scale = 40 (custom.py:1155,1382; mushr.em.xml:16-18); <= 0 means 40 */
     const double *fan_dirs;         /* optional [n_rays][2]: body-frame unit directions of the rangefinder fan; NULL = the sites of
                                        template/mushr.em.xml:112-117, (sin phi_j, -cos phi_j) with phi_j = radians(360 / n_rays * j - 90).
-                                       RANGEFINDER mode uses their binary32 roundings, FAKELIDAR mode the binary64 values. */
+                                       FAKELIDAR mode uses the binary64 values as they are.  RANGEFINDER mode uses their binary32 roundings -- for
+                                       fan_dirs == NULL and an even n_rays with the second half of the table written as the exact negation of the
+                                       first (site j + n/2 looks exactly opposite to site j: the sweep derives a ray from its opposite); a caller's
+                                       fan is rounded entry by entry. */
     FtgpTrack track;
     FtgpVehicle vehicle;
 } FtgpConfig;
