@@ -755,10 +755,34 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
         CREATE_TRY(hipMemcpy(simg.data() + head + cover, e->d_cover + stride, std::min(cover, sizeof(float) * stride), hipMemcpyDeviceToHost));
         CREATE_TRY(hipMemcpy(e->d_stage, simg.data(), simg.size(), hipMemcpyHostToDevice));
     }
-    {   // device image of the parameter block
-        std::vector<unsigned char> pimg((size_t)pad16(sizeof(DeviceParams)), 0);
-        memcpy(pimg.data(), &P, sizeof(DeviceParams));
+    {   // device image of the parameter block, and behind it the sweep's task table (DeviceParams::task_tab): draw g is task g / cars_per_block of
+        // car slot g % cars_per_block, with everything the draw and the delivery need precomputed
+        const size_t head = (size_t)pad16(sizeof(DeviceParams));
+        const int cpb = P.cars_per_block, ntasks = cpb * P.tasks_per_car, R = P.n_rays, halfR = R / 2;
+        if (P.tasks_per_car > 256 || R > 0x4000) { ftgp_destroy(e); return fail(FTGP_ERR_ARG, "internal: the task table's fields are too narrow for this fan%s"); }
+        std::vector<int32_t> tt(2 * 4 * (size_t)ntasks, 0);
+        auto wclass = [&](int first, int lim) {          // rays first .. min(first + 63, lim - 1) against the window [eighth, R - eighth)
+            const int last = std::min(first + FTGP_WAVE, lim) - 1, lo = P.eighth, hi = R - P.eighth;
+            if (last < lo || first >= hi || lo >= hi) return 0;
+            return (first >= lo && last < hi) ? 1 : 2;
+        };
+        for (int g = 0; g < ntasks; ++g) {
+            const int kidx = g / cpb, c = g % cpb, ent = P.group_order[kidx], j0 = ent & 0xffff, kind = ent >> 16;
+            const int w0 = kind == 2 ? 2 : wclass(j0, kind == 1 ? halfR : R), w1 = kind == 1 ? wclass(j0 + halfR, R) : 0;
+            const uint32_t plain = (uint32_t)j0 | (uint32_t)kind << 14 | (uint32_t)c << 16;
+            int32_t* a = &tt[4 * (size_t)g];
+            int32_t* b = &tt[4 * (size_t)(ntasks + g)];
+            a[0] = (int32_t)(plain | (uint32_t)w0 << 20 | (uint32_t)w1 << 22 | (uint32_t)(j0 == 0 ? 1 : 0) << 24);
+            b[0] = (int32_t)plain;
+            a[1] = b[1] = c * (int)sizeof(LidarFrame) | kidx << 16;
+            a[2] = b[2] = c * P.ranges_stride * 4;
+            a[3] = b[3] = 4 * (c * P.win_floats + (P.eighth & 3) - P.eighth);
+        }
+        std::vector<unsigned char> pimg(head + sizeof(int32_t) * tt.size() + 16, 0);
         CREATE_TRY(hipMalloc(&e->d_params, pimg.size()));
+        P.task_tab = reinterpret_cast<const int32_t*>(reinterpret_cast<unsigned char*>(e->d_params) + head);
+        memcpy(pimg.data(), &P, sizeof(DeviceParams));
+        memcpy(pimg.data() + head, tt.data(), sizeof(int32_t) * tt.size());
         CREATE_TRY(hipMemcpy(e->d_params, pimg.data(), pimg.size(), hipMemcpyHostToDevice));
     }
 #undef CREATE_TRY

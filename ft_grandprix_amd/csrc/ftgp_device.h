@@ -118,6 +118,13 @@ struct DeviceParams {
                                   // track, sideways rays hit the corridor wall at once): first ray | kind << 16, kind 0 = one group of 64
                                   // consecutive rays, 1 = that group and the opposite one (first ray + n/2), 2 = the short ends of both halves in
                                   // one group (lanes 0..31 / 32..63); read with scalar loads
+    const int32_t* task_tab;      // [2][cars_per_block * tasks_per_car][4] the sweep's draws, one 16-byte scalar load each (lidar_groups; behind this block in device memory):
+                                  //   [0] first ray (14 bits) | kind << 14 | car slot << 16 | window class of the first / second group << 20 / 22 | (the first group holds ray 0) << 24
+                                  //       (window class: 0 = no ray of the group lies in the drivers' scan window, 1 = every ray does, 2 = test per ray)
+                                  //   [1] byte offset of the car's LidarFrame in a frame buffer | rank of the task among the car's << 16
+                                  //   [2] byte offset of the car's row of ranges from the workgroup's first row
+                                  //   [3] byte offset, in a scan buffer, at which sample j of the car sits when 4 j is added: row + ((eighth & 3) - eighth) floats
+                                  // the second table is for launches whose drivers do not read the scan: window classes 0, no ray 0
 };
 
 // vehicle constants as staged into LDS

@@ -329,19 +329,22 @@ __device__ __forceinline__ void lidar_groups(const DeviceParams& P, ScalarParams
 {
     typedef __attribute__((address_space(1))) float* global_f32;
     typedef __attribute__((address_space(1))) unsigned char* global_u8w;
-    const int R = G->n_rays, half = R >> 1, cpb = G->cars_per_block, ntasks = cpb * G->tasks_per_car;
-    const int W = G->width, H = G->height, fstride = G->fstride, stride = G->ranges_stride;
-    const uint32_t plane256 = G->plane256, gmagic = G->group_magic;
+    struct alignas(16) Task { int32_t x, y, z, w; };
+    typedef const __attribute__((address_space(4))) Task* ScalarTasks;
+    const int R = G->n_rays, half = R >> 1, ntasks = G->cars_per_block * G->tasks_per_car;
+    const int W = G->width, H = G->height, fstride = G->fstride;
+    const uint32_t plane256 = G->plane256;
     const int eighth = G->eighth, win_floats = G->win_floats;
     const float isx = G->inv_px_x_f, isy = G->inv_px_y_f, thr = 0.5f - G->snap_eps, nsf = G->slice_factor;
     const float r0 = sgpr(L.veh->ring_radius_f);
     const void* field = G->field;
-    const global_f32 ranges = (global_f32)G->ranges + (size_t)ci0 * stride;
+    const ScalarTasks tasks = (ScalarTasks)G->task_tab + (scan_lds ? 0 : ntasks);      // (the second table: no ray goes to a scan window)
+    const global_u8w ranges = (global_u8w)((global_f32)G->ranges + (size_t)ci0 * G->ranges_stride);      // the workgroup's first row
     const int mmask_stride = G->mmask_stride;
     const int lane = lane_here();
     const bool all_safe = sgpr(pool[4]) == 0;        // every ray of this sweep starts on the image (frame_write): no test per ray
     sweep_priority(second_half);
-    for (int round = 0; round < (1 << 16); ++round) {          // (bounded: a safety net)
+    for (;;) {                   // (ends: every draw moves the counter on)
         STAMP(ta);
         // (a task is drawn when the wave is ready for it, not earlier: drawing the next one before the march -- to hide the LDS round
         // trip -- reserves work behind a wave that may be on a long group, and cost 6 % on the headline and 12 % on config 2)
@@ -349,18 +352,23 @@ __device__ __forceinline__ void lidar_groups(const DeviceParams& P, ScalarParams
         if (lane == 0) g = atomicAdd(pool, 1);
         g = __builtin_amdgcn_readfirstlane(g);
         if (g >= ntasks) break;
-        // Draw g = the kidx-th most expensive task (rays along the car's axis march longest, see group_order) of car slot g % cpb: the
-        // long tasks of every car go first, so that the waves of a workgroup end a sweep within a short group of each other.
-        const int kidx = gmagic ? (int)__umulhi((uint32_t)g, gmagic) : g, c = g - kidx * cpb;
-        const int ent = G->group_order[kidx];                     // first ray | kind << 16 (wave-uniform)
-        const int j0 = ent & 0xffff, kind = ent >> 16;            // kind 0: one group; 1: a group and its opposite; 2: both halves in one group
+        // Draw g = the (g / cars_per_block)-th most expensive task (rays along the car's axis march longest, see group_order) of car slot
+        // g % cars_per_block: the long tasks of every car go first, so that the waves of a workgroup end a sweep within a short group of each
+        // other.  Everything about the draw that ftgp_create can know -- first ray, kind, car slot, where the car's LiDAR frame, its row of
+        // ranges and its scan window start, whether the group's rays lie in the drivers' window -- comes as ONE 16-byte scalar load
+        // (ftgp_task_entry; round 5: a division by multiplication, a table read and three 32- and 64-bit address products per group used to
+        // stand here and in the delivery: a third of the kernel's scalar instructions).
+        Task task; { const uint32_t gu = (uint32_t)g; task.x = tasks[gu].x; task.y = tasks[gu].y; task.z = tasks[gu].z; task.w = tasks[gu].w; }
+        const int j0 = task.x & 0x3fff, kind = (task.x >> 14) & 3, c = (task.x >> 16) & 15;     // kind 0: one group; 1: a group and its opposite; 2: both halves in one group
         int j; bool mine;
         if (kind == 2) { j = j0 + (lane & 31) + (lane >= 32 ? half : 0); mine = (lane & 31) < half - j0; }
         else { j = j0 + lane; mine = j < (kind == 1 ? half : R); }
         mine = mine && c < ncars_here;               // (a ragged last workgroup draws tasks of cars it does not have)
+        const LidarFrame* frame = reinterpret_cast<const LidarFrame*>(reinterpret_cast<const unsigned char*>(frames) + (task.y & 0xffff));
         FtgpRay ray;
-        float du = 0.0f, dv = 0.0f, dxw = 0.0f, dyw = 0.0f;
-        uint32_t sector = 0;
+        float du, dv, dxw, dyw;
+        uint32_t sector;
+        asm volatile("" : "=v"(du), "=v"(dv), "=v"(dxw), "=v"(dyw), "=v"(sector));      // (lanes that hold no ray never look at these: no moves to define them)
         // march the lanes' rays and deliver their ranges: ftgp_ray_range(), the inter-vehicle test, the stores
         auto finish = [&](bool active, int pass) {
             if (!active) return;
@@ -373,8 +381,9 @@ __device__ __forceinline__ void lidar_groups(const DeviceParams& P, ScalarParams
                 // Rays also see the other cars of the env (a9).  One record per env-mate (PairCull, written with the frames) rules a
                 // mate out with a dot product: it can only be touched if it lies in front of the ray and within `cull` of its line.
                 const PairCull* mates = pairs + c * FTGP_PAIR_STRIDE;
-                const int slot0 = sgpr(frames[c].slot0);
+                const int slot0 = sgpr(frame->slot0);
                 // ... and one byte per (car, group) says which mates the group's rays can see at all (mate_masks): mostly none
+                const int kidx = task.y >> 16;
                 uint32_t mm = (uint32_t)sgpr((int)mmask[c * mmask_stride + 2 * kidx + pass]);
                 while (mm) {
                     const int k = __builtin_ctz(mm); mm &= mm - 1u;
@@ -390,17 +399,25 @@ __device__ __forceinline__ void lidar_groups(const DeviceParams& P, ScalarParams
             }
             // every range leaves for HBM now, 64 consecutive floats per wave (one 256-byte row segment); the window the on-device drivers
             // read next step -- ranges[0] and ranges[eighth : n - eighth] -- is kept in LDS as well
-            *(global_f32)((global_u8w)(ranges + c * stride) + ((uint32_t)j << 2)) = r;
-            if (scan_lds) {
-                const int jw = j - eighth;
-                const bool in_window = (unsigned)jw < (unsigned)(R - 2 * eighth);
-                float* row = scan_rows + c * win_floats;
-                if (in_window) row[(eighth & 3) + jw] = r;
-                if (j == 0) row[win_floats - 1] = r;
+            const uint32_t j4 = (uint32_t)j << 2;
+            *(global_f32)(ranges + (j4 + (uint32_t)task.z)) = r;
+            // task.w: byte offset of the car's scan row + ((eighth & 3) - eighth) floats, so that sample j sits at task.w + 4 j.  Whether the
+            // group's rays lie inside the window, outside it or across one of its ends is the task's to know (two bits per pass; all zero in
+            // the table of a launch whose drivers do not read the scan).  The rare cases sit behind scalar branches that the optimiser is kept
+            // from turning into selects.
+            const int wclass = (task.x >> (20 + 2 * pass)) & 3;
+            if (wclass) {                        // (a group across an end of the window sends its outside rays to a spare word: one store site, no masks)
+                float* dst = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(scan_rows) + task.w + j4);
+                if (wclass == 2) { asm volatile(""); dst = (unsigned)(j - eighth) < (unsigned)(R - 2 * eighth) ? dst : reinterpret_cast<float*>(pool + 6); }
+                *dst = r;
+            }
+            if ((task.x & (1 << 24)) && pass == 0) {          // the group holds ray 0: ranges[0] (fast.py:135) sits in the last float of the row
+                asm volatile("");
+                if (j == 0) *reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(scan_rows) + task.w + 4 * (win_floats - 1 - (eighth & 3) + eighth)) = r;
             }
         };
         if (mine) {
-            const float4 f4 = *reinterpret_cast<const float4*>(frames + c);      // u0, v0, chf, shf (one address for the wave)
+            const float4 f4 = *reinterpret_cast<const float4*>(frame);      // u0, v0, chf, shf (one address for the wave)
             const float2 bd = L.ray[j];
             dxw = fmaf(f4.z, bd.x, -(f4.w * bd.y));
             dyw = fmaf(f4.w, bd.x, f4.z * bd.y);
@@ -425,14 +442,14 @@ __device__ __forceinline__ void lidar_groups(const DeviceParams& P, ScalarParams
         if (kind == 1) {                 // the same rays turned round: ray j + n/2 = -(ray j), exactly
             if (mine) {
                 j += half;
-                const float4 f4 = *reinterpret_cast<const float4*>(frames + c);
+                const float2 f2 = *reinterpret_cast<const float2*>(frame);
                 du = -du; dv = -dv; dxw = -dxw; dyw = -dyw;
-                const float pu = fmaf(du, -r0, f4.x);
-                const float pv = fmaf(dv, -r0, f4.y);
+                const float pu = fmaf(du, -r0, f2.x);
+                const float pv = fmaf(dv, -r0, f2.y);
                 ftgp_ray_place(ray, pu, pv, du, dv, ray.ivx, ray.ivy, sector ^ 3u, W, H, fstride, plane256, true, &P.sector_tab[0][0]);
                 if (!all_safe) {
                     ftgp_ray_park_if_outside(ray, pu, pv, W, H);
-                    ray.result = (f4.x == -INFINITY) ? 0.0f : -1.0f;
+                    ray.result = (f2.x == -INFINITY) ? 0.0f : -1.0f;
                 }
             }
             finish(mine, 1);
