@@ -678,6 +678,12 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
         const double cx = std::max(fabs(v.box_xmin), fabs(v.box_xmax)), cy = std::max(fabs(v.box_ymin), fabs(v.box_ymax));
         const double rmax = std::max(sqrt(cx * cx + cy * cy), sqrt(v.lidar_x * v.lidar_x + v.lidar_y * v.lidar_y) + v.lidar_ring_radius);
         vl.cull_radius = (float)(1.1 * rmax);
+        {   // the puck inside the box with at least 1e-3 to spare on every side (MuSHR: 0.016, tricycle: 0.0175): coordinates in a mate's frame are below the
+            // map's 40 units, so binary32 rounding of the two tests is below 1e-5 -- the circle can never come out ahead of the box
+            const double m = 1e-3, r = v.lidar_ring_radius;
+            vl.puck_in_box = (v.lidar_x - r >= v.box_xmin + m && v.lidar_x + r <= v.box_xmax - m && v.lidar_y - r >= v.box_ymin + m && v.lidar_y + r <= v.box_ymax - m &&
+                              !getenv("FTGP_PUCK_TEST")) ? 1 : 0;
+        }
         vl.box_xmin_f = (float)v.box_xmin; vl.box_xmax_f = (float)v.box_xmax; vl.box_ymin_f = (float)v.box_ymin; vl.box_ymax_f = (float)v.box_ymax;
         vl.lidar_x_f = (float)v.lidar_x; vl.lidar_y_f = (float)v.lidar_y; vl.ring_radius_f = (float)v.lidar_ring_radius;
         memcpy(vimg.data(), &vl, sizeof vl);

@@ -131,7 +131,9 @@ struct DeviceParams {
 struct VehLds {
     FtgpVehicle v;
     double wheel_load[4];
-    float cull_radius, pad;       // every part of a car that a ray can see lies within this distance of the car's origin
+    float cull_radius;            // every part of a car that a ray can see lies within this distance of the car's origin
+    int32_t puck_in_box;          // the LiDAR puck's disc lies inside the chassis box by a margin far above binary32 rounding: a ray then meets the box no later than
+                                  // the puck, min(box, puck) is the box's time to the bit, and ray_vs_car() leaves the circle test (a square root) out
     // binary32 of the constants the inter-vehicle ray test uses (the conversions the specification makes per test, made once)
     float box_xmin_f, box_xmax_f, box_ymin_f, box_ymax_f, lidar_x_f, lidar_y_f, ring_radius_f, pad_f;
 };

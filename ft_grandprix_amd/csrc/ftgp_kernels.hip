@@ -163,7 +163,7 @@ __device__ __forceinline__ void rcp_abs2(float x, float y, float& rx, float& ry)
     rx = p; ry = q;
 }
 
-// Ray against another car: chassis box (slab test) and LiDAR puck (circle), binary32 -- the specification's arithmetic with
+// Ray against another car: chassis box (slab test) and LiDAR puck (circle; left out where it cannot win, VehLds::puck_in_box), binary32 -- the specification's arithmetic with
 // everything that does not depend on the ray taken from where it already exists: (bx, by) = mate's origin - my LiDAR centre is
 // the pair record's (its negation is the specification's (float)(centre - origin): binary64 subtraction and the conversion
 // are odd functions), the mate's heading in binary32 is its LiDAR frame's, the vehicle constants in binary32 are VehLds',
@@ -195,7 +195,7 @@ __device__ __forceinline__ float ray_vs_car(const VehLds* V, const LidarFrame* b
             if (t < best) best = t;
         }
     }
-    {
+    if (!sgpr(V->puck_in_box)) {            // (wave-uniform; with the puck inside the box -- both bundled vehicles -- the box's time is the minimum already: VehLds)
         const float px = lx - V->lidar_x_f, py = ly - V->lidar_y_f;
         const float bq = fmaf(px, ldx, py * ldy);
         const float cq = fmaf(px, px, py * py) - r0 * r0;
@@ -237,8 +237,9 @@ __device__ __forceinline__ void sweep_priority(bool second_half)
 // body needs no live mask, finished rays hold their cell and crossing time for free (and burn no vector lanes), and the loop
 // closes with one branch on exec: 21 vector (the look-up's six included; rounds 1-4: 23) + 3 scalar-side instructions per iteration, + the
 // near-boundary path.  Priced with tools/issue_calib.sh an iteration costs a SIMD about 85 cycles: two thirds of it selects, compares and conversions.
-// In: exec = the lanes that hold a ray; mx, my = cells travelled (0 at the origin), s = crossing time into the cell (0 at the origin).
-// Out: w = entry of the terminal cell (0 = wall, FTGP_FIELD_OUT = ring), s = crossing time into it, exec as on entry.
+// In: exec = the lanes that hold a ray, every one on its start cell; s = 0 (the crossing time into the start cell).
+// Out: mx, my = the terminal cell (cells travelled from the start cell), w = its entry (0 = wall, FTGP_FIELD_OUT = ring), s = crossing time
+// into it, exec as on entry.  The first look-up and jump are peeled (the start cell is (0, 0): no zeroes to set, no byte-select adds).
 // The arithmetic is ftgp_ray_step / ftgp_ray_fix / ftgp_ray_commit of ftgp_march.h, instruction for instruction: a crossing time is
 // fma((float)boundary, iv, -c) -- boundaries counted from the ray's own start cell (round 5; rounds 1-4: convert, subtract the origin's
 // absolute coordinate, multiply).  du, dv come in signed (the body reads their magnitudes through the operand modifier).
@@ -261,56 +262,80 @@ __device__ __forceinline__ void march_all(int& mx, int& my, float& s, uint32_t& 
         "v_mad_i32_i24 %[a], %[my], %[ay], %[base]\n\t"                  /* entry offset = ftgp_ray_offset() */ \
         "v_mad_i32_i24 %[a], %[mx], %[ax], %[a]\n\t" \
         FTGP_MARCH_LOAD("%[a]")
-        FTGP_MARCH_LOAD("%[base]")                                        // the start cell
+        // crossing times of the box's far edges, the axis that is reached first, the landing estimate and its distance from a pixel boundary
+#define FTGP_MARCH_BODY(fix) \
+        "v_cvt_f32_i32_e32 %[a], %[c]\n\t" \
+        "v_cvt_f32_i32_e32 %[b], %[d]\n\t" \
+        "v_fma_f32 %[a], %[a], %[ivx], -%[cx]\n\t"                       /* sX = fma((float)xe, ivx, -cx): the box's far edge is the xe-th boundary */ \
+        "v_fma_f32 %[b], %[b], %[ivy], -%[cy]\n\t"                       /* sY */ \
+        "v_cmp_lt_f32_e64 %[stepx], %[a], %[b]\n\t"                      /* the x edge of the box is reached first (a tie steps in y) */ \
+        "v_fma_f32 %[e], |%[dv]|, %[a], %[gv]\n\t"                       /* landing estimate after an x-jump ... */ \
+        "v_fma_f32 %[f], |%[du]|, %[b], %[gu]\n\t"                       /* ... after a y-jump */ \
+        "v_cndmask_b32_e64 %[s], %[b], %[a], %[stepx]\n\t"               /* s = sn (a lane that ended on this lookup left exec above and keeps its s) */ \
+        "v_cndmask_b32_e64 %[e], %[f], %[e], %[stepx]\n\t"               /* v */ \
+        "v_cvt_flr_i32_f32_e32 %[h], %[e]\n\t"                           /* t = floor(v) */ \
+        "v_fract_f32_e32 %[f], %[e]\n\t" \
+        "v_add_f32_e32 %[f], -0.5, %[f]\n\t" \
+        "v_cmp_gt_f32_e64 vcc, |%[f]|, %[thr]\n\t"                       /* within eps of a pixel boundary: the specification's comparisons decide */ \
+        "s_cbranch_vccnz " fix "\n"
+        // ftgp_ray_fix() for the lanes in vcc; cur = the select that yields the transverse coordinate of the cell the ray stands on
+#define FTGP_MARCH_FIX(cur, back) \
+        "s_and_saveexec_b64 %[sv], vcc\n\t" \
+        "v_cndmask_b32_e64 %[a], %[cx], %[cy], %[stepx]\n\t"             /* transverse c ... */ \
+        "v_cndmask_b32_e64 %[b], %[ivx], %[ivy], %[stepx]\n\t"           /* ... reciprocal ... */ \
+        cur                                                              /* ... current cell ... */ \
+        "v_cndmask_b32_e64 %[i], %[c], %[d], %[stepx]\n\t" \
+        "v_add_u32_e32 %[i], -1, %[i]\n\t"                               /* ... last cell of the box's span */ \
+        "v_rndne_f32_e32 %[e], %[e]\n\t"                                 /* the boundary in doubt */ \
+        "v_fma_f32 %[a], %[e], %[b], -%[a]\n\t"                          /* its crossing time, the specification's way */ \
+        "v_cvt_i32_f32_e32 %[b], %[e]\n\t" \
+        "v_cmp_lt_f32_e64 vcc, %[a], %[s]\n\t" \
+        "v_cmp_le_f32_e64 %[sq], %[a], %[s]\n\t" \
+        "s_and_b64 %[sq], %[sq], %[stepx]\n\t"                           /* crossed: S <= sn after an x-jump, S < sn after a y-jump */ \
+        "s_or_b64 vcc, vcc, %[sq]\n\t" \
+        "v_cndmask_b32_e64 %[a], -1, 0, vcc\n\t" \
+        "v_add_u32_e32 %[h], %[b], %[a]\n\t"                             /* the cell beyond the boundary if crossed, else the one before */ \
+        "v_med3_i32 %[h], %[h], %[f], %[i]\n\t"                          /* inside the box's span */ \
+        "s_mov_b64 exec, %[sv]\n\t" \
+        "s_branch " back "\n"
+        // The start cell and the first jump, peeled: the ray stands on cell (0, 0), so the box's far corner is the entry's two bytes as they
+        // come (a mask and a shift for two byte-select adds) and nobody has to set mx, my to zero first -- they are written here before anything reads them.
+        "global_load_ushort %[w], %[base], %[field]\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        "v_and_b32_e32 %[c], 0xff, %[w]\n\t"                              // xe = kx
+        "v_lshrrev_b32_e32 %[d], 8, %[w]\n\t"                             // ye = ky
+        "v_cmpx_ne_u32_e32 vcc, 0, %[c]\n\t"                              // kx == 0: the ray starts in a wall (or was parked on a ring cell)
+        "s_cbranch_execz L_march_done_%=\n\t"
+        FTGP_MARCH_BODY("L_march_fix0_%=")
+        "L_march_commit0_%=:\n\t"
+        "v_cndmask_b32_e64 %[mx], %[h], %[c], %[stepx]\n\t"
+        "v_cndmask_b32_e64 %[my], %[d], %[h], %[stepx]\n\t"
+        FTGP_MARCH_LOOKUP
         "s_cbranch_execz L_march_done_%=\n"
         "L_march_loop_%=:\n\t"
-        "v_cvt_f32_i32_e32 %[a], %[c]\n\t"
-        "v_cvt_f32_i32_e32 %[b], %[d]\n\t"
-        "v_fma_f32 %[a], %[a], %[ivx], -%[cx]\n\t"                       // sX = fma((float)xe, ivx, -cx): the box's far edge is the xe-th boundary
-        "v_fma_f32 %[b], %[b], %[ivy], -%[cy]\n\t"                       // sY
-        "v_cmp_lt_f32_e64 %[stepx], %[a], %[b]\n\t"                      // the x edge of the box is reached first (a tie steps in y)
-        "v_fma_f32 %[e], |%[dv]|, %[a], %[gv]\n\t"                       // landing estimate after an x-jump ...
-        "v_fma_f32 %[f], |%[du]|, %[b], %[gu]\n\t"                       // ... after a y-jump
-        "v_cndmask_b32_e64 %[s], %[b], %[a], %[stepx]\n\t"               // s = sn (a lane that ended on this lookup left exec above and keeps its s)
-        "v_cndmask_b32_e64 %[e], %[f], %[e], %[stepx]\n\t"               // v
-        "v_cvt_flr_i32_f32_e32 %[h], %[e]\n\t"                           // t = floor(v)
-        "v_fract_f32_e32 %[f], %[e]\n\t"
-        "v_add_f32_e32 %[f], -0.5, %[f]\n\t"
-        "v_cmp_gt_f32_e64 vcc, |%[f]|, %[thr]\n\t"                       // within eps of a pixel boundary: the specification's comparisons decide
-        "s_cbranch_vccnz L_march_fix_%=\n"
+        FTGP_MARCH_BODY("L_march_fix_%=")
         "L_march_commit_%=:\n\t"
         "v_cndmask_b32_e64 %[mx], %[h], %[c], %[stepx]\n\t"
         "v_cndmask_b32_e64 %[my], %[d], %[h], %[stepx]\n\t"
         FTGP_MARCH_LOOKUP                                                 // (the loop is rotated: its one taken branch is the one that closes it)
         "s_cbranch_execnz L_march_loop_%=\n\t"
         "s_branch L_march_done_%=\n"
-        "L_march_fix_%=:\n\t"                                            // ftgp_ray_fix() for the lanes in vcc
-        "s_and_saveexec_b64 %[sv], vcc\n\t"
-        "v_cndmask_b32_e64 %[a], %[cx], %[cy], %[stepx]\n\t"             // transverse c ...
-        "v_cndmask_b32_e64 %[b], %[ivx], %[ivy], %[stepx]\n\t"           // ... reciprocal ...
-        "v_cndmask_b32_e64 %[f], %[mx], %[my], %[stepx]\n\t"             // ... current cell ...
-        "v_cndmask_b32_e64 %[i], %[c], %[d], %[stepx]\n\t"
-        "v_add_u32_e32 %[i], -1, %[i]\n\t"                               // ... last cell of the box's span
-        "v_rndne_f32_e32 %[e], %[e]\n\t"                                 // the boundary in doubt
-        "v_fma_f32 %[a], %[e], %[b], -%[a]\n\t"                          // its crossing time, the specification's way
-        "v_cvt_i32_f32_e32 %[b], %[e]\n\t"
-        "v_cmp_lt_f32_e64 vcc, %[a], %[s]\n\t"
-        "v_cmp_le_f32_e64 %[sq], %[a], %[s]\n\t"
-        "s_and_b64 %[sq], %[sq], %[stepx]\n\t"                           // crossed: S <= sn after an x-jump, S < sn after a y-jump
-        "s_or_b64 vcc, vcc, %[sq]\n\t"
-        "v_cndmask_b32_e64 %[a], -1, 0, vcc\n\t"
-        "v_add_u32_e32 %[h], %[b], %[a]\n\t"                             // the cell beyond the boundary if crossed, else the one before
-        "v_med3_i32 %[h], %[h], %[f], %[i]\n\t"                          // inside the box's span
-        "s_mov_b64 exec, %[sv]\n\t"
-        "s_branch L_march_commit_%=\n"
+        "L_march_fix_%=:\n\t"
+        FTGP_MARCH_FIX("v_cndmask_b32_e64 %[f], %[mx], %[my], %[stepx]\n\t", "L_march_commit_%=")
+        "L_march_fix0_%=:\n\t"
+        FTGP_MARCH_FIX("v_mov_b32_e32 %[f], 0\n\t", "L_march_commit0_%=")
         "L_march_done_%=:\n\t"
         "s_mov_b64 exec, %[ex0]"
-        : [mx] "+v"(mx), [my] "+v"(my), [s] "+v"(s), [w] "+v"(w),
+        : [mx] "=&v"(mx), [my] "=&v"(my), [s] "+v"(s), [w] "=&v"(w),
           [a] "=&v"(a), [b] "=&v"(b), [c] "=&v"(c), [d] "=&v"(d), [e] "=&v"(e), [f] "=&v"(f), [h] "=&v"(h), [i] "=&v"(i),
           [stepx] "=&s"(stepx), [sv] "=&s"(sv), [sq] "=&s"(sq), [ex0] "=&s"(ex0)
         : [gu] "v"(gu), [gv] "v"(gv), [cx] "v"(cx), [cy] "v"(cy), [ivx] "v"(ivx), [ivy] "v"(ivy), [du] "v"(du), [dv] "v"(dv),
           [base] "v"(base), [ax] "v"(ax), [ay] "v"(ay), [thr] "s"(thr), [field] "s"(field)
         : "vcc", "scc", "memory");
+#undef FTGP_MARCH_LOAD
+#undef FTGP_MARCH_LOOKUP
+#undef FTGP_MARCH_BODY
+#undef FTGP_MARCH_FIX
 }
 
 // The sweep of one step for all cars of the workgroup, by every wave, in GROUPS of 64 consecutive rays of one car: a wave draws the
@@ -372,7 +397,7 @@ __device__ __forceinline__ void lidar_groups(const DeviceParams& P, ScalarParams
         // march the lanes' rays and deliver their ranges: ftgp_ray_range(), the inter-vehicle test, the stores
         auto finish = [&](bool active, int pass) {
             if (!active) return;
-            uint32_t w = FTGP_FIELD_OUT;
+            uint32_t w;
             STAMP(tb);
             march_all(ray.mx, ray.my, ray.s, w, ray.gu, ray.gv, ray.cx, ray.cy, ray.ivx, ray.ivy, du, dv, ray.base, ray.ax, ray.ay, thr, field);
             STAMP(tc); STAMP_ADD(10, tc - tb); STAMP_ADD(9, 1);
