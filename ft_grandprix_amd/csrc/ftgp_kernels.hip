@@ -244,26 +244,15 @@ __device__ __forceinline__ void sweep_priority(bool second_half)
 // fma((float)boundary, iv, -c) -- boundaries counted from the ray's own start cell (round 5; rounds 1-4: convert, subtract the origin's
 // absolute coordinate, multiply).  du, dv come in signed (the body reads their magnitudes through the operand modifier).
 // off0: the byte offset of the start cell's entry (= base).
-__device__ __forceinline__ void march_all(int& mx, int& my, float& s, uint32_t& w, float gu, float gv, float cx, float cy, float ivx, float ivy, float du, float dv,
+__device__ __forceinline__ void march_all(float& s, uint32_t& w, float gu, float gv, float cx, float cy, float ivx, float ivy, float du, float dv,
                                           int base, int ax, int ay, float thr /* 0.5f - eps */, const void* field)
 {
-    int a, b, c, d, e, f, h, i;
+    int a, b, c, d, e, f, h, i, mx, my, nx, ny;
     uint64_t stepx, sv, sq, ex0;
     asm volatile(
         "s_mov_b64 %[ex0], exec\n\t"
-        // the look-up of the cell a ray stands on: far corner of its box, "is it a box at all"
-#define FTGP_MARCH_LOAD(addr) \
-        "global_load_ushort %[w], " addr ", %[field]\n\t" \
-        "s_waitcnt vmcnt(0)\n\t" \
-        "v_add_u32_sdwa %[c], %[mx], %[w] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"     /* xe = mx + kx */ \
-        "v_add_u32_sdwa %[d], %[my], %[w] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t"     /* ye = my + ky */ \
-        "v_cmpx_ne_u32_e32 vcc, %[c], %[mx]\n\t"                         /* kx == 0: wall or ring cell -- the lane is done */
-#define FTGP_MARCH_LOOKUP \
-        "v_mad_i32_i24 %[a], %[my], %[ay], %[base]\n\t"                  /* entry offset = ftgp_ray_offset() */ \
-        "v_mad_i32_i24 %[a], %[mx], %[ax], %[a]\n\t" \
-        FTGP_MARCH_LOAD("%[a]")
-        // crossing times of the box's far edges, the axis that is reached first, the landing estimate and its distance from a pixel boundary
-#define FTGP_MARCH_BODY(fix) \
+        // crossing times of the box's far edges, the axis that is reached first, the landing estimate and its floor
+#define FTGP_MARCH_BODY \
         "v_cvt_f32_i32_e32 %[a], %[c]\n\t" \
         "v_cvt_f32_i32_e32 %[b], %[d]\n\t" \
         "v_fma_f32 %[a], %[a], %[ivx], -%[cx]\n\t"                       /* sX = fma((float)xe, ivx, -cx): the box's far edge is the xe-th boundary */ \
@@ -273,13 +262,27 @@ __device__ __forceinline__ void march_all(int& mx, int& my, float& s, uint32_t& 
         "v_fma_f32 %[f], |%[du]|, %[b], %[gu]\n\t"                       /* ... after a y-jump */ \
         "v_cndmask_b32_e64 %[s], %[b], %[a], %[stepx]\n\t"               /* s = sn (a lane that ended on this lookup left exec above and keeps its s) */ \
         "v_cndmask_b32_e64 %[e], %[f], %[e], %[stepx]\n\t"               /* v */ \
-        "v_cvt_flr_i32_f32_e32 %[h], %[e]\n\t"                           /* t = floor(v) */ \
+        "v_cvt_flr_i32_f32_e32 %[h], %[e]\n\t"                           /* t = floor(v) */
+        // the new cell (NX, NY) and its look-up, issued on the landing estimate; THEN the estimate's distance from a pixel boundary, in the shadow of
+        // the load: within eps the specification's comparisons decide (fix) and the look-up is issued again for those lanes
+#define FTGP_MARCH_MOVE(NX, NY, fix) \
+        "v_cndmask_b32_e64 " NX ", %[h], %[c], %[stepx]\n\t" \
+        "v_cndmask_b32_e64 " NY ", %[d], %[h], %[stepx]\n\t" \
+        "v_mad_i32_i24 %[a], " NY ", %[ay], %[base]\n\t"                 /* entry offset = ftgp_ray_offset() */ \
+        "v_mad_i32_i24 %[a], " NX ", %[ax], %[a]\n\t" \
+        "global_load_ushort %[w], %[a], %[field]\n\t" \
         "v_fract_f32_e32 %[f], %[e]\n\t" \
         "v_add_f32_e32 %[f], -0.5, %[f]\n\t" \
-        "v_cmp_gt_f32_e64 vcc, |%[f]|, %[thr]\n\t"                       /* within eps of a pixel boundary: the specification's comparisons decide */ \
+        "v_cmp_gt_f32_e64 vcc, |%[f]|, %[thr]\n\t" \
         "s_cbranch_vccnz " fix "\n"
+        // the entry of the cell the ray stands on: far corner of its box; kx == 0 -- a wall or ring cell -- and the lane is done
+#define FTGP_MARCH_ARRIVE(NX, NY) \
+        "s_waitcnt vmcnt(0)\n\t" \
+        "v_add_u32_sdwa %[c], " NX ", %[w] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t"     /* xe = mx + kx */ \
+        "v_add_u32_sdwa %[d], " NY ", %[w] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t"     /* ye = my + ky */ \
+        "v_cmpx_ne_u32_e32 vcc, %[c], " NX "\n\t"
         // ftgp_ray_fix() for the lanes in vcc; cur = the select that yields the transverse coordinate of the cell the ray stands on
-#define FTGP_MARCH_FIX(cur, back) \
+#define FTGP_MARCH_FIX(cur, NX, NY, back) \
         "s_and_saveexec_b64 %[sv], vcc\n\t" \
         "v_cndmask_b32_e64 %[a], %[cx], %[cy], %[stepx]\n\t"             /* transverse c ... */ \
         "v_cndmask_b32_e64 %[b], %[ivx], %[ivy], %[stepx]\n\t"           /* ... reciprocal ... */ \
@@ -296,45 +299,57 @@ __device__ __forceinline__ void march_all(int& mx, int& my, float& s, uint32_t& 
         "v_cndmask_b32_e64 %[a], -1, 0, vcc\n\t" \
         "v_add_u32_e32 %[h], %[b], %[a]\n\t"                             /* the cell beyond the boundary if crossed, else the one before */ \
         "v_med3_i32 %[h], %[h], %[f], %[i]\n\t"                          /* inside the box's span */ \
+        "v_cndmask_b32_e64 " NX ", %[h], %[c], %[stepx]\n\t"             /* the cell and its look-up again (the first look-up's answer arrives first and is overwritten) */ \
+        "v_cndmask_b32_e64 " NY ", %[d], %[h], %[stepx]\n\t" \
+        "v_mad_i32_i24 %[a], " NY ", %[ay], %[base]\n\t" \
+        "v_mad_i32_i24 %[a], " NX ", %[ax], %[a]\n\t" \
+        "global_load_ushort %[w], %[a], %[field]\n\t" \
         "s_mov_b64 exec, %[sv]\n\t" \
         "s_branch " back "\n"
         // The start cell and the first jump, peeled: the ray stands on cell (0, 0), so the box's far corner is the entry's two bytes as they
-        // come (a mask and a shift for two byte-select adds) and nobody has to set mx, my to zero first -- they are written here before anything reads them.
+        // come (a mask and a shift for two byte-select adds) and nobody has to set the cell to zero first.
         "global_load_ushort %[w], %[base], %[field]\n\t"
         "s_waitcnt vmcnt(0)\n\t"
         "v_and_b32_e32 %[c], 0xff, %[w]\n\t"                              // xe = kx
         "v_lshrrev_b32_e32 %[d], 8, %[w]\n\t"                             // ye = ky
         "v_cmpx_ne_u32_e32 vcc, 0, %[c]\n\t"                              // kx == 0: the ray starts in a wall (or was parked on a ring cell)
         "s_cbranch_execz L_march_done_%=\n\t"
-        FTGP_MARCH_BODY("L_march_fix0_%=")
-        "L_march_commit0_%=:\n\t"
-        "v_cndmask_b32_e64 %[mx], %[h], %[c], %[stepx]\n\t"
-        "v_cndmask_b32_e64 %[my], %[d], %[h], %[stepx]\n\t"
-        FTGP_MARCH_LOOKUP
+        FTGP_MARCH_BODY
+        FTGP_MARCH_MOVE("%[mx]", "%[my]", "L_march_fix0_%=")
+        "L_march_arrive0_%=:\n\t"
+        FTGP_MARCH_ARRIVE("%[mx]", "%[my]")
         "s_cbranch_execz L_march_done_%=\n"
+        // the loop, two iterations per trip: the cell alternates between (mx, my) and (nx, ny), so that the near-boundary path still finds the
+        // cell the ray came from after the move has been made
         "L_march_loop_%=:\n\t"
-        FTGP_MARCH_BODY("L_march_fix_%=")
-        "L_march_commit_%=:\n\t"
-        "v_cndmask_b32_e64 %[mx], %[h], %[c], %[stepx]\n\t"
-        "v_cndmask_b32_e64 %[my], %[d], %[h], %[stepx]\n\t"
-        FTGP_MARCH_LOOKUP                                                 // (the loop is rotated: its one taken branch is the one that closes it)
+        FTGP_MARCH_BODY
+        FTGP_MARCH_MOVE("%[nx]", "%[ny]", "L_march_fix1_%=")
+        "L_march_arrive1_%=:\n\t"
+        FTGP_MARCH_ARRIVE("%[nx]", "%[ny]")
+        "s_cbranch_execz L_march_done_%=\n\t"
+        FTGP_MARCH_BODY
+        FTGP_MARCH_MOVE("%[mx]", "%[my]", "L_march_fix2_%=")
+        "L_march_arrive2_%=:\n\t"
+        FTGP_MARCH_ARRIVE("%[mx]", "%[my]")
         "s_cbranch_execnz L_march_loop_%=\n\t"
         "s_branch L_march_done_%=\n"
-        "L_march_fix_%=:\n\t"
-        FTGP_MARCH_FIX("v_cndmask_b32_e64 %[f], %[mx], %[my], %[stepx]\n\t", "L_march_commit_%=")
         "L_march_fix0_%=:\n\t"
-        FTGP_MARCH_FIX("v_mov_b32_e32 %[f], 0\n\t", "L_march_commit0_%=")
+        FTGP_MARCH_FIX("v_mov_b32_e32 %[f], 0\n\t", "%[mx]", "%[my]", "L_march_arrive0_%=")
+        "L_march_fix1_%=:\n\t"
+        FTGP_MARCH_FIX("v_cndmask_b32_e64 %[f], %[mx], %[my], %[stepx]\n\t", "%[nx]", "%[ny]", "L_march_arrive1_%=")
+        "L_march_fix2_%=:\n\t"
+        FTGP_MARCH_FIX("v_cndmask_b32_e64 %[f], %[nx], %[ny], %[stepx]\n\t", "%[mx]", "%[my]", "L_march_arrive2_%=")
         "L_march_done_%=:\n\t"
         "s_mov_b64 exec, %[ex0]"
-        : [mx] "=&v"(mx), [my] "=&v"(my), [s] "+v"(s), [w] "=&v"(w),
+        : [s] "+v"(s), [w] "=&v"(w), [mx] "=&v"(mx), [my] "=&v"(my), [nx] "=&v"(nx), [ny] "=&v"(ny),
           [a] "=&v"(a), [b] "=&v"(b), [c] "=&v"(c), [d] "=&v"(d), [e] "=&v"(e), [f] "=&v"(f), [h] "=&v"(h), [i] "=&v"(i),
           [stepx] "=&s"(stepx), [sv] "=&s"(sv), [sq] "=&s"(sq), [ex0] "=&s"(ex0)
         : [gu] "v"(gu), [gv] "v"(gv), [cx] "v"(cx), [cy] "v"(cy), [ivx] "v"(ivx), [ivy] "v"(ivy), [du] "v"(du), [dv] "v"(dv),
           [base] "v"(base), [ax] "v"(ax), [ay] "v"(ay), [thr] "s"(thr), [field] "s"(field)
         : "vcc", "scc", "memory");
-#undef FTGP_MARCH_LOAD
-#undef FTGP_MARCH_LOOKUP
 #undef FTGP_MARCH_BODY
+#undef FTGP_MARCH_MOVE
+#undef FTGP_MARCH_ARRIVE
 #undef FTGP_MARCH_FIX
 }
 
@@ -399,7 +414,7 @@ __device__ __forceinline__ void lidar_groups(const DeviceParams& P, ScalarParams
             if (!active) return;
             uint32_t w;
             STAMP(tb);
-            march_all(ray.mx, ray.my, ray.s, w, ray.gu, ray.gv, ray.cx, ray.cy, ray.ivx, ray.ivy, du, dv, ray.base, ray.ax, ray.ay, thr, field);
+            march_all(ray.s, w, ray.gu, ray.gv, ray.cx, ray.cy, ray.ivx, ray.ivy, du, dv, ray.base, ray.ax, ray.ay, thr, field);
             STAMP(tc); STAMP_ADD(10, tc - tb); STAMP_ADD(9, 1);
             float r = (w == 0u) ? fabsf(ray.s) : ray.result;
             if (MULTI && FTGP_DIAG_RUN_MATES) {
