@@ -244,10 +244,11 @@ __device__ __forceinline__ void sweep_priority(bool second_half)
 // fma((float)boundary, iv, -c) -- boundaries counted from the ray's own start cell (round 5; rounds 1-4: convert, subtract the origin's
 // absolute coordinate, multiply).  du, dv come in signed (the body reads their magnitudes through the operand modifier).
 // off0: the byte offset of the start cell's entry (= base).
-__device__ __forceinline__ void march_all(float& s, uint32_t& w, float gu, float gv, float cx, float cy, float ivx, float ivy, float du, float dv,
+__device__ __forceinline__ void march_all(float& s, uint32_t& w, float pu, float pv, float ivx, float ivy, float du, float dv,
                                           int base, int ax, int ay, float thr /* 0.5f - eps */, const void* field)
 {
     int a, b, c, d, e, f, h, i, mx, my, nx, ny;
+    float gu, gv, cx, cy;
     uint64_t stepx, sv, sq, ex0;
     asm volatile(
         "s_mov_b64 %[ex0], exec\n\t"
@@ -309,6 +310,19 @@ __device__ __forceinline__ void march_all(float& s, uint32_t& w, float gu, float
         // The start cell and the first jump, peeled: the ray stands on cell (0, 0), so the box's far corner is the entry's two bytes as they
         // come (a mask and a shift for two byte-select adds) and nobody has to set the cell to zero first.
         "global_load_ushort %[w], %[base], %[field]\n\t"
+        // ... and in the shadow of that load what the jumps need of the ray's origin (the tail of ftgp_ray_place): its offset inside the start cell seen in
+        // the direction of travel, g, and c = g * iv; the crossing time into the start cell is 0
+        "v_fract_f32_e32 %[gu], %[pu]\n\t"                               // p - floor(p): exact for every p >= 0 (an origin off the image is parked: it ends on this look-up)
+        "v_fract_f32_e32 %[gv], %[pv]\n\t"
+        "v_sub_f32_e32 %[a], 1.0, %[gu]\n\t"
+        "v_sub_f32_e32 %[b], 1.0, %[gv]\n\t"
+        "v_cmp_gt_f32_e32 vcc, 0, %[du]\n\t"                             // (a component of -0 counts as not negative: it never steps)
+        "v_cndmask_b32_e32 %[gu], %[gu], %[a], vcc\n\t"
+        "v_cmp_gt_f32_e32 vcc, 0, %[dv]\n\t"
+        "v_cndmask_b32_e32 %[gv], %[gv], %[b], vcc\n\t"
+        "v_mul_f32_e32 %[cx], %[gu], %[ivx]\n\t"
+        "v_mul_f32_e32 %[cy], %[gv], %[ivy]\n\t"
+        "v_mov_b32_e32 %[s], 0\n\t"
         "s_waitcnt vmcnt(0)\n\t"
         "v_and_b32_e32 %[c], 0xff, %[w]\n\t"                              // xe = kx
         "v_lshrrev_b32_e32 %[d], 8, %[w]\n\t"                             // ye = ky
@@ -341,10 +355,11 @@ __device__ __forceinline__ void march_all(float& s, uint32_t& w, float gu, float
         FTGP_MARCH_FIX("v_cndmask_b32_e64 %[f], %[nx], %[ny], %[stepx]\n\t", "%[mx]", "%[my]", "L_march_arrive2_%=")
         "L_march_done_%=:\n\t"
         "s_mov_b64 exec, %[ex0]"
-        : [s] "+v"(s), [w] "=&v"(w), [mx] "=&v"(mx), [my] "=&v"(my), [nx] "=&v"(nx), [ny] "=&v"(ny),
+        : [s] "=&v"(s), [w] "=&v"(w), [mx] "=&v"(mx), [my] "=&v"(my), [nx] "=&v"(nx), [ny] "=&v"(ny),
           [a] "=&v"(a), [b] "=&v"(b), [c] "=&v"(c), [d] "=&v"(d), [e] "=&v"(e), [f] "=&v"(f), [h] "=&v"(h), [i] "=&v"(i),
+          [gu] "=&v"(gu), [gv] "=&v"(gv), [cx] "=&v"(cx), [cy] "=&v"(cy),
           [stepx] "=&s"(stepx), [sv] "=&s"(sv), [sq] "=&s"(sq), [ex0] "=&s"(ex0)
-        : [gu] "v"(gu), [gv] "v"(gv), [cx] "v"(cx), [cy] "v"(cy), [ivx] "v"(ivx), [ivy] "v"(ivy), [du] "v"(du), [dv] "v"(dv),
+        : [pu] "v"(pu), [pv] "v"(pv), [ivx] "v"(ivx), [ivy] "v"(ivy), [du] "v"(du), [dv] "v"(dv),
           [base] "v"(base), [ax] "v"(ax), [ay] "v"(ay), [thr] "s"(thr), [field] "s"(field)
         : "vcc", "scc", "memory");
 #undef FTGP_MARCH_BODY
@@ -406,15 +421,15 @@ __device__ __forceinline__ void lidar_groups(const DeviceParams& P, ScalarParams
         mine = mine && c < ncars_here;               // (a ragged last workgroup draws tasks of cars it does not have)
         const LidarFrame* frame = reinterpret_cast<const LidarFrame*>(reinterpret_cast<const unsigned char*>(frames) + (task.y & 0xffff));
         FtgpRay ray;
-        float du, dv, dxw, dyw;
+        float du, dv, dxw, dyw, opu, opv;              // opu, opv: the ray's origin in pixels
         uint32_t sector;
-        asm volatile("" : "=v"(du), "=v"(dv), "=v"(dxw), "=v"(dyw), "=v"(sector));      // (lanes that hold no ray never look at these: no moves to define them)
+        asm volatile("" : "=v"(du), "=v"(dv), "=v"(dxw), "=v"(dyw), "=v"(opu), "=v"(opv), "=v"(sector));      // (lanes that hold no ray never look at these: no moves to define them)
         // march the lanes' rays and deliver their ranges: ftgp_ray_range(), the inter-vehicle test, the stores
         auto finish = [&](bool active, int pass) {
             if (!active) return;
             uint32_t w;
             STAMP(tb);
-            march_all(ray.s, w, ray.gu, ray.gv, ray.cx, ray.cy, ray.ivx, ray.ivy, du, dv, ray.base, ray.ax, ray.ay, thr, field);
+            march_all(ray.s, w, opu, opv, ray.ivx, ray.ivy, du, dv, ray.base, ray.ax, ray.ay, thr, field);
             STAMP(tc); STAMP_ADD(10, tc - tb); STAMP_ADD(9, 1);
             float r = (w == 0u) ? fabsf(ray.s) : ray.result;
             if (MULTI && FTGP_DIAG_RUN_MATES) {
@@ -465,6 +480,7 @@ __device__ __forceinline__ void lidar_groups(const DeviceParams& P, ScalarParams
             dv = -(dyw * isy);
             const float pu = fmaf(du, -r0, f4.x);
             const float pv = fmaf(dv, -r0, f4.y);
+            opu = pu; opv = pv;
             float ivx, ivy;
             rcp_abs2<true>(du, dv, ivx, ivy);
             ray.result = -1.0f;
@@ -486,6 +502,7 @@ __device__ __forceinline__ void lidar_groups(const DeviceParams& P, ScalarParams
                 du = -du; dv = -dv; dxw = -dxw; dyw = -dyw;
                 const float pu = fmaf(du, -r0, f2.x);
                 const float pv = fmaf(dv, -r0, f2.y);
+                opu = pu; opv = pv;
                 ftgp_ray_place(ray, pu, pv, du, dv, ray.ivx, ray.ivy, sector ^ 3u, W, H, fstride, plane256, true, &P.sector_tab[0][0]);
                 if (!all_safe) {
                     ftgp_ray_park_if_outside(ray, pu, pv, W, H);
