@@ -261,7 +261,6 @@ __device__ __forceinline__ void march_all(float& s, uint32_t& w, float pu, float
         "v_cmp_lt_f32_e64 %[stepx], %[a], %[b]\n\t"                      /* the x edge of the box is reached first (a tie steps in y) */ \
         "v_fma_f32 %[e], |%[dv]|, %[a], %[gv]\n\t"                       /* landing estimate after an x-jump ... */ \
         "v_fma_f32 %[f], |%[du]|, %[b], %[gu]\n\t"                       /* ... after a y-jump */ \
-        "v_cndmask_b32_e64 %[s], %[b], %[a], %[stepx]\n\t"               /* s = sn (a lane that ended on this lookup left exec above and keeps its s) */ \
         "v_cndmask_b32_e64 %[e], %[f], %[e], %[stepx]\n\t"               /* v */ \
         "v_cvt_flr_i32_f32_e32 %[h], %[e]\n\t"                           /* t = floor(v) */
         // the new cell (NX, NY) and its look-up, issued on the landing estimate; THEN the estimate's distance from a pixel boundary, in the shadow of
@@ -269,9 +268,10 @@ __device__ __forceinline__ void march_all(float& s, uint32_t& w, float pu, float
 #define FTGP_MARCH_MOVE(NX, NY, fix) \
         "v_cndmask_b32_e64 " NX ", %[h], %[c], %[stepx]\n\t" \
         "v_cndmask_b32_e64 " NY ", %[d], %[h], %[stepx]\n\t" \
-        "v_mad_i32_i24 %[a], " NY ", %[ay], %[base]\n\t"                 /* entry offset = ftgp_ray_offset() */ \
-        "v_mad_i32_i24 %[a], " NX ", %[ax], %[a]\n\t" \
-        "global_load_ushort %[w], %[a], %[field]\n\t" \
+        "v_mad_i32_i24 %[i], " NY ", %[ay], %[base]\n\t"                 /* entry offset = ftgp_ray_offset() */ \
+        "v_mad_i32_i24 %[i], " NX ", %[ax], %[i]\n\t" \
+        "global_load_ushort %[w], %[i], %[field]\n\t" \
+        "v_cndmask_b32_e64 %[s], %[b], %[a], %[stepx]\n\t"               /* s = sn, the crossing time into the new cell (a lane that ended on the last lookup left exec and keeps its s) */ \
         "v_fract_f32_e32 %[f], %[e]\n\t" \
         "v_add_f32_e32 %[f], -0.5, %[f]\n\t" \
         "v_cmp_gt_f32_e64 vcc, |%[f]|, %[thr]\n\t" \
@@ -302,9 +302,9 @@ __device__ __forceinline__ void march_all(float& s, uint32_t& w, float pu, float
         "v_med3_i32 %[h], %[h], %[f], %[i]\n\t"                          /* inside the box's span */ \
         "v_cndmask_b32_e64 " NX ", %[h], %[c], %[stepx]\n\t"             /* the cell and its look-up again (the first look-up's answer arrives first and is overwritten) */ \
         "v_cndmask_b32_e64 " NY ", %[d], %[h], %[stepx]\n\t" \
-        "v_mad_i32_i24 %[a], " NY ", %[ay], %[base]\n\t" \
-        "v_mad_i32_i24 %[a], " NX ", %[ax], %[a]\n\t" \
-        "global_load_ushort %[w], %[a], %[field]\n\t" \
+        "v_mad_i32_i24 %[i], " NY ", %[ay], %[base]\n\t" \
+        "v_mad_i32_i24 %[i], " NX ", %[ax], %[i]\n\t" \
+        "global_load_ushort %[w], %[i], %[field]\n\t" \
         "s_mov_b64 exec, %[sv]\n\t" \
         "s_branch " back "\n"
         // The start cell and the first jump, peeled: the ray stands on cell (0, 0), so the box's far corner is the entry's two bytes as they
@@ -402,7 +402,8 @@ __device__ __forceinline__ void lidar_groups(const DeviceParams& P, ScalarParams
     for (;;) {                   // (ends: every draw moves the counter on)
         STAMP(ta);
         // (a task is drawn when the wave is ready for it, not earlier: drawing the next one before the march -- to hide the LDS round
-        // trip -- reserves work behind a wave that may be on a long group, and cost 6 % on the headline and 12 % on config 2)
+        // trip -- reserves work behind a wave that may be on a long group, and cost 6 % on the headline and 12 % on config 2; drawing it
+        // between the last march and its delivery is within noise: profiles/round5/ab_setup_latency_experiments.log)
         int g = 0;
         if (lane == 0) g = atomicAdd(pool, 1);
         g = __builtin_amdgcn_readfirstlane(g);
