@@ -536,15 +536,23 @@ __device__ __forceinline__ void lidar_groups(const DeviceParams& P, ScalarParams
 // is given up with what it has accumulated (a caller's fan may hold a zero direction: the reference would loop for ever).
 __device__ __forceinline__ void march_fake(double& x, double& y, double& dist, int& bad, double dx, double dy, int W, int H, const double* dt)
 {
-    double n = 0.0, t;
+    double n = 0.0, t, u;
     int xi, yi, a, b;
     uint64_t sq, ex0;
     int guard = 1 << 16;
+    // The look-up of an iteration is ISSUED before its tests are made (round 5, like march_all's): on an index clamped to the table -- for a ray
+    // that passes the tests the clamp changes nothing, for one that fails them the answer is never looked at -- so that the dependent chain from
+    // one look-up to the next is convert, clamp, index, load instead of convert and a dozen tests first; the tests run in the load's shadow.
     asm volatile(
         "s_mov_b64 %[ex0], exec\n"
         "L_fake_loop_%=:\n\t"
         "v_cvt_i32_f64_e32 %[xi], %[x]\n\t"                              // int(x): truncation toward zero
         "v_cvt_i32_f64_e32 %[yi], %[y]\n\t"
+        "v_med3_i32 %[a], %[xi], 0, %[Wm1]\n\t"
+        "v_med3_i32 %[b], %[yi], 0, %[Hm1]\n\t"
+        "v_mad_u32_u24 %[a], %[b], %[W], %[a]\n\t"
+        "v_lshlrev_b32_e32 %[a], 3, %[a]\n\t"
+        "global_load_dwordx2 %[n], %[a], %[dt]\n\t"
         "v_add_u32_e32 %[a], %[W], %[xi]\n\t"
         "v_add_u32_e32 %[b], %[H], %[yi]\n\t"
         "v_cmp_le_u32_e32 vcc, %[W2], %[a]\n\t"                          // IndexError: not (-W <= int(x) < W) ...
@@ -557,26 +565,23 @@ __device__ __forceinline__ void march_fake(double& x, double& y, double& dist, i
         "s_or_b64 vcc, vcc, %[sq]\n\t"
         "s_andn2_b64 exec, exec, vcc\n\t"                                // those rays are done
         "s_cbranch_execz L_fake_done_%=\n\t"
-        "v_mad_u32_u24 %[a], %[yi], %[W], %[xi]\n\t"
-        "v_lshlrev_b32_e32 %[a], 3, %[a]\n\t"
-        "global_load_dwordx2 %[n], %[a], %[dt]\n\t"
         "s_sub_u32 %[guard], %[guard], 1\n\t"
         "s_cbranch_scc1 L_fake_done_%=\n\t"
         "s_waitcnt vmcnt(0)\n\t"
         "v_cmpx_lt_f64_e32 vcc, 2.0, %[n]\n\t"                           // while nearest > eps
         "s_cbranch_execz L_fake_done_%=\n\t"
-        "v_add_f64 %[dist], %[dist], %[n]\n\t"                           // distance += nearest
         "v_mul_f64 %[t], %[dx], %[n]\n\t"
+        "v_mul_f64 %[u], %[dy], %[n]\n\t"
         "v_add_f64 %[x], %[x], %[t]\n\t"                                 // x += dx * nearest
-        "v_mul_f64 %[t], %[dy], %[n]\n\t"
-        "v_add_f64 %[y], %[y], %[t]\n\t"                                 // y += dy * nearest
+        "v_add_f64 %[y], %[y], %[u]\n\t"                                 // y += dy * nearest
+        "v_add_f64 %[dist], %[dist], %[n]\n\t"                           // distance += nearest
         "s_branch L_fake_loop_%=\n"
         "L_fake_done_%=:\n\t"
         "s_waitcnt vmcnt(0)\n\t"
         "s_mov_b64 exec, %[ex0]"
-        : [x] "+v"(x), [y] "+v"(y), [dist] "+v"(dist), [bad] "+v"(bad), [n] "+v"(n), [t] "=&v"(t), [xi] "=&v"(xi), [yi] "=&v"(yi), [a] "=&v"(a), [b] "=&v"(b),
+        : [x] "+v"(x), [y] "+v"(y), [dist] "+v"(dist), [bad] "+v"(bad), [n] "+v"(n), [t] "=&v"(t), [u] "=&v"(u), [xi] "=&v"(xi), [yi] "=&v"(yi), [a] "=&v"(a), [b] "=&v"(b),
           [sq] "=&s"(sq), [ex0] "=&s"(ex0), [guard] "+s"(guard)
-        : [dx] "v"(dx), [dy] "v"(dy), [W] "s"(W), [H] "s"(H), [W2] "s"(2 * W), [H2] "s"(2 * H), [dt] "s"(dt)
+        : [dx] "v"(dx), [dy] "v"(dy), [W] "s"(W), [H] "s"(H), [W2] "s"(2 * W), [H2] "s"(2 * H), [Wm1] "s"(W - 1), [Hm1] "s"(H - 1), [dt] "s"(dt)
         : "vcc", "scc", "memory");
 }
 
