@@ -1096,28 +1096,53 @@ __device__ __forceinline__ void dynamics_lanes(const DeviceParams& P, const Lds&
     wave_lds_sync();
     SUBSTAMP(4);
     // ---- K3: distances = ((path - xpos)**2).sum(1); closest = distances.argmin() (first minimum), then the race-state update
-    const double x = st->x, y = st->y;
-    int idx = r * (FTGP_PATH_POINTS / 4);
-    double best;
-    {
-        const double dx = L.path[2 * idx] - x, dy = L.path[2 * idx + 1] - y;
-        best = dx * dx + dy * dy;
+    int idx; double best;
+    bool upd = on && r == 0;             // the lane that updates the car's race state, its car slot and record
+    int upd_c = c; CarCore* upd_st = st;
+    if (ncars_here * 16 <= FTGP_WAVE) {
+        // A small batch's workgroup holds at most four cars and its step IS the driver -> dynamics chain: sixteen lanes per car then walk seven
+        // points each instead of four lanes twenty-five (lanes 14 and 15: two and none), and two more exchanges -- rotations by 8 and 4 inside the
+        // row of 16 lanes -- bring every lane the car's first minimum.
+        const int c16 = lane >> 4, q = lane & 15;
+        const bool on16 = c16 < ncars_here;
+        CarCore* st16 = L.cars + (on16 ? c16 : 0);
+        const double x = st16->x, y = st16->y;
+        const int first = q * 7, last = first + 7 < FTGP_PATH_POINTS ? first + 7 : FTGP_PATH_POINTS;
+        idx = first < FTGP_PATH_POINTS ? first : 0x7fffffff; best = INFINITY;
+        #pragma unroll 1
+        for (int i = first; i < last; ++i) {
+            const double dx = L.path[2 * i] - x, dy = L.path[2 * i + 1] - y;
+            const double d = dx * dx + dy * dy;
+            if (i == first || d < best) { best = d; idx = i; }
+        }
+        quad_argmin_step<0x128>(best, idx);      // row_ror:8
+        quad_argmin_step<0x124>(best, idx);      // row_ror:4
+        quad_argmin_step<0x4E>(best, idx);       // quad_perm [2,3,0,1]
+        quad_argmin_step<0xB1>(best, idx);       // quad_perm [1,0,3,2]
+        upd = on16 && q == 0; upd_c = c16; upd_st = st16;
+    } else {
+        const double x = st->x, y = st->y;
+        idx = r * (FTGP_PATH_POINTS / 4);
+        {
+            const double dx = L.path[2 * idx] - x, dy = L.path[2 * idx + 1] - y;
+            best = dx * dx + dy * dy;
+        }
+        #pragma unroll 1
+        for (int i = idx + 1; i < (r + 1) * (FTGP_PATH_POINTS / 4); ++i) {
+            const double dx = L.path[2 * i] - x, dy = L.path[2 * i + 1] - y;
+            const double d = dx * dx + dy * dy;
+            if (d < best) { best = d; idx = i; }
+        }
+        // the car's four lanes: exchanges inside the quad by DPP (quad_perm [1,0,3,2], then [2,3,0,1]), no LDS crossbar trip.
+        // The lower index wins ties; a NaN never wins (the oracle's `d < best` is false for it too)
+        quad_argmin_step<0xB1>(best, idx);
+        quad_argmin_step<0x4E>(best, idx);
     }
-    #pragma unroll 1
-    for (int i = idx + 1; i < (r + 1) * (FTGP_PATH_POINTS / 4); ++i) {
-        const double dx = L.path[2 * i] - x, dy = L.path[2 * i + 1] - y;
-        const double d = dx * dx + dy * dy;
-        if (d < best) { best = d; idx = i; }
-    }
-    // the car's four lanes: exchanges inside the quad by DPP (quad_perm [1,0,3,2], then [2,3,0,1]), no LDS crossbar trip.
-    // The lower index wins ties; a NaN never wins (the oracle's `d < best` is false for it too)
-    quad_argmin_step<0xB1>(best, idx);
-    quad_argmin_step<0x4E>(best, idx);
     SUBSTAMP(5);
-    if (on && r == 0) {
-        Race rc; race_load(rc, st);
-        progress_update(P, rc, L.steps[c], idx, best, P.cars[ci0 + c].times, &st->start);
-        race_store(rc, st);
+    if (upd) {
+        Race rc; race_load(rc, upd_st);
+        progress_update(P, rc, L.steps[upd_c], idx, best, P.cars[ci0 + upd_c].times, &upd_st->start);
+        race_store(rc, upd_st);
     }
     wave_lds_sync();
     SUBSTAMP(6);
