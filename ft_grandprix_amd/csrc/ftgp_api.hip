@@ -522,7 +522,6 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
     P.snap_eps = ftgp_snap_eps(t.width, t.height);
     { hipDeviceProp_t prop; CREATE_TRY(hipGetDeviceProperties(&prop, e->device)); P.n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256; }
     P.edge_margin = (float)(v.lidar_ring_radius * std::max(P.inv_px_x, P.inv_px_y) * 1.001 + 2.0);
-    P.ray_magic = (uint32_t)((0x100000000ull + (uint64_t)cfg->n_rays - 1) / (uint64_t)cfg->n_rays);
     if ((cfg->n_rays + FTGP_WAVE - 1) / FTGP_WAVE > FTGP_MAX_GROUPS) { ftgp_destroy(e); return fail(FTGP_ERR_ARG, "n_rays above 16384 is not supported%s"); }
 
     // workgroup shape: whole envs, at most 16 cars (K1 / K3 run on the lanes of one wave), two workgroups per CU
@@ -552,13 +551,6 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
         }
         if (getenv("FTGP_VERBOSE"))
             fprintf(stderr, "ftgp_create: %d cars x %d waves per workgroup, %d B of LDS (cap %d)\n", cpb, wpb, lds_layout(P, cpb, wpb), lds_cap);
-        // pool index -> car slot by multiplication: exact for every index the sweep can produce
-        for (uint32_t g = 0; g < (uint32_t)(cpb * P.n_rays); ++g)
-            if ((uint32_t)(((uint64_t)g * P.ray_magic) >> 32) != g / (uint32_t)P.n_rays) {
-                snprintf(g_err, sizeof g_err, "internal: ray_magic is not exact for n_rays = %d", P.n_rays);
-                ftgp_destroy(e);
-                return FTGP_ERR_ARG;
-            }
     }
 #define FTGP_BIG_LDS(M, F, R) CREATE_TRY(hipFuncSetAttribute((const void*)ftgp_step_kernel<M, F, R>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
     FTGP_BIG_LDS(false, false, false); FTGP_BIG_LDS(true, false, false); FTGP_BIG_LDS(false, false, true); FTGP_BIG_LDS(true, false, true);
@@ -598,10 +590,6 @@ int ftgp_create(const FtgpConfig* cfg, FtgpEnv** out)
             if (j0 < halfR) tasks.push_back(j0 | ((halfR - j0 <= FTGP_WAVE / 2 ? 2 : 1) << 16));
         }
         P.tasks_per_car = (int)tasks.size();
-        const uint32_t cpbu = (uint32_t)P.cars_per_block;
-        P.group_magic = cpbu == 1 ? 0u : (uint32_t)((0x100000000ull + cpbu - 1) / cpbu);
-        for (uint32_t g = 0; P.group_magic && g < cpbu * (uint32_t)(2 * P.tasks_per_car + 4) + 64; ++g)
-            if ((uint32_t)(((uint64_t)g * P.group_magic) >> 32) != g / cpbu) { ftgp_destroy(e); return fail(FTGP_ERR_ARG, "internal: group_magic is not exact%s"); }
         // expected march length of a task ~ how far its rays look along the car's axis: |cos| of the angle between the group's middle ray
         // and the axis (ray 0 looks backwards, ray n/2 ahead); ties keep index order
         std::vector<std::pair<double, int>> key;

@@ -64,7 +64,7 @@ struct DeviceParams {
     double px_size_x, px_size_y, origin_x, origin_y, inv_px_x, inv_px_y;
     float inv_px_x_f, inv_px_y_f;
     float snap_eps;               // the march re-checks a landing point with the exact comparisons within this distance of a pixel boundary
-    uint32_t ray_magic;           // ceil(2^32 / n_rays): pool index -> (car slot, ray) without a division
+    uint32_t reserved_m0;         // (rounds 2 - 4: the ray pool's division by multiplication)
     uint32_t plane256;            // bytes per (padded) sector plane of the box field / 256
     int32_t n_sectors;            // direction sectors of this handle's box field: 8 x (1, 2, 4 or 8 slope slices per octant)
     float slice_factor;           // FTGP_SLICE_FACTOR(FTGP_SLOPE_SLICES): a ray's sector is found among all FTGP_SECTORS, sector_tab maps it to planes
@@ -84,7 +84,7 @@ struct DeviceParams {
     int32_t lidar_mode, pad_e;
     int32_t tasks_per_car;        // the sweep's work list per car (lidar_groups): groups of 64 consecutive rays, or pairs of opposite groups
     float group_cg, group_sg;     // cos / sin of the half-width of a ray group as mate_masks() needs it (cg < -1: no bound, e.g. a caller's fan)
-    uint32_t group_magic;         // ceil(2^32 / cars_per_block) (0 for one car per block): group draw -> (rank of the group, car slot) without a division
+    uint32_t reserved_m1;         // (rounds 4 - 5: the group draw's division by multiplication; a draw now reads its task descriptor, task_tab)
     const uint16_t* field;        // [n_sectors][height + 2][width + 2] box entries (ftgp_march.h), HBM/L2
     const uint32_t* bits;         // [height][words_per_row] wall bitmap
     const uint32_t* nearbits;     // [height][words_per_row] wall bitmap dilated by contact_reach (early-out of the wall contact)

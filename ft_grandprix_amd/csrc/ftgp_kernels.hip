@@ -592,30 +592,31 @@ __device__ __forceinline__ void lidar_fake(ScalarParams G, const LidarFrame* fra
 {
     typedef __attribute__((address_space(1))) float* global_f32;
     typedef __attribute__((address_space(1))) unsigned char* global_u8w;
-    const int R = G->n_rays, half = R >> 1, cpb = G->cars_per_block, ntasks = cpb * G->tasks_per_car;
-    const int W = G->width, H = G->height, stride = G->ranges_stride;
-    const uint32_t gmagic = G->group_magic;
+    struct alignas(16) Task { int32_t x, y, z, w; };             // DeviceParams::task_tab (see lidar_groups)
+    typedef const __attribute__((address_space(4))) Task* ScalarTasks;
+    const int R = G->n_rays, half = R >> 1, ntasks = G->cars_per_block * G->tasks_per_car;
+    const int W = G->width, H = G->height;
     const int eighth = G->eighth, win_floats = G->win_floats;
     const double s = G->map_size;
     const double* dt = G->edt;
     const double* __restrict__ fan = G->fan_dirs;
-    const global_f32 ranges = (global_f32)G->ranges + (size_t)ci0 * stride;
+    const ScalarTasks tasks = (ScalarTasks)G->task_tab + (scan_lds ? 0 : ntasks);
+    const global_u8w ranges = (global_u8w)((global_f32)G->ranges + (size_t)ci0 * G->ranges_stride);
     const int lane = lane_here();
-    for (int round = 0; round < (1 << 16); ++round) {          // (bounded: a safety net)
+    for (;;) {
         int g = 0;
         if (lane == 0) g = atomicAdd(pool, 1);
         g = __builtin_amdgcn_readfirstlane(g);
         if (g >= ntasks) break;
-        const int kidx = gmagic ? (int)__umulhi((uint32_t)g, gmagic) : g, c = g - kidx * cpb;
-        const int ent = G->group_order[kidx];                     // first ray | kind << 16 (wave-uniform): see lidar_groups()
-        const int j0 = ent & 0xffff, kind = ent >> 16;
+        Task task; { const uint32_t gu = (uint32_t)g; task.x = tasks[gu].x; task.y = tasks[gu].y; task.z = tasks[gu].z; task.w = tasks[gu].w; }
+        const int j0 = task.x & 0x3fff, kind = (task.x >> 14) & 3, c = (task.x >> 16) & 15;
         int j; bool mine;
         if (kind == 2) { j = j0 + (lane & 31) + (lane >= 32 ? half : 0); mine = (lane & 31) < half - j0; }
         else { j = j0 + lane; mine = j < (kind == 1 ? half : R); }
         mine = mine && c < ncars_here;
+        const LidarFrame* f = reinterpret_cast<const LidarFrame*>(reinterpret_cast<const unsigned char*>(frames) + (task.y & 0xffff));
         for (int pass = 0; pass < (kind == 1 ? 2 : 1); ++pass, j += half) {
             if (!mine) continue;
-            const LidarFrame* f = frames + c;
             float r = 0.0f;                                       // a finished car's rangefinders are switched off (custom.py:1436-1439): its scan reads 0
             if (!f->finished) {
                 const double ch = f->x, sh = f->y;                // FAKELIDAR frames: heading (cos, sin) in binary64 (frame_write)
@@ -626,13 +627,17 @@ __device__ __forceinline__ void lidar_fake(ScalarParams G, const LidarFrame* fra
                 march_fake(x, y, distance, bad, dxw, -dyw, W, H, dt);      // image rows grow downwards
                 r = bad ? -1.0f : (float)((distance / (double)W) * s);     // ranges /= original_width; ranges *= s (custom.py:1392-1393)
             }
-            *(global_f32)((global_u8w)(ranges + c * stride) + ((uint32_t)j << 2)) = r;
-            if (scan_lds) {
-                const int jw = j - eighth;
-                const bool in_window = (unsigned)jw < (unsigned)(R - 2 * eighth);
-                float* row = scan_rows + c * win_floats;
-                if (in_window) row[(eighth & 3) + jw] = r;
-                if (j == 0) row[win_floats - 1] = r;
+            const uint32_t j4 = (uint32_t)j << 2;
+            *(global_f32)(ranges + (j4 + (uint32_t)task.z)) = r;
+            const int wclass = (task.x >> (20 + 2 * pass)) & 3;   // the delivery of lidar_groups(): window classes from the task
+            if (wclass) {
+                float* dst = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(scan_rows) + task.w + j4);
+                if (wclass == 2) { asm volatile(""); dst = (unsigned)(j - eighth) < (unsigned)(R - 2 * eighth) ? dst : reinterpret_cast<float*>(pool + 6); }
+                *dst = r;
+            }
+            if ((task.x & (1 << 24)) && pass == 0) {
+                asm volatile("");
+                if (j == 0) *reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(scan_rows) + task.w + 4 * (win_floats - 1 - (eighth & 3) + eighth)) = r;
             }
         }
     }

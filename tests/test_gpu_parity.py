@@ -318,6 +318,28 @@ def test_enlarged_vehicle_box_is_seen(product, oracle):
         assert_same_state(g, o)
 
 
+@pytest.mark.parametrize("how", ["puck_outside_the_box", "switch"])
+def test_inter_vehicle_test_with_the_pucks_circle(product, oracle, how, monkeypatch):
+    """The inter-vehicle ray test leaves the LiDAR puck's circle out when it lies inside the chassis box (both bundled vehicles: the box's time
+    is then the minimum to the bit).  The circle's code path stays what the oracle computes: a vehicle whose puck sticks out of its box behind
+    (so that rays from behind meet the puck first), and the bundled vehicle with the test forced on (FTGP_PUCK_TEST=1)."""
+    t = load_track("track")
+    v = product.default_vehicle()
+    if how == "switch":
+        monkeypatch.setenv("FTGP_PUCK_TEST", "1")
+    else:
+        v.box_xmin = -0.06                       # the puck spans x in [-0.0825, -0.0225]
+    kw = dict(n_envs=12, cars_per_env=4, n_rays=1080, spawn_mode=0, lap_target=3, vehicle=v)
+    g, o = both(product, oracle, t, **kw)
+    with g, o, capi.Env(oracle, t, **dict(kw, vehicle=None)) as plain:
+        g.step(1); o.step(1); plain.step(1)
+        np.testing.assert_array_equal(g.lidar(), o.lidar())
+        if how != "switch":
+            assert (g.lidar() != plain.lidar()).any()                  # the shortened box is seen as such (rays from behind now end on the puck)
+        g.rollout("fast", 200); o.rollout("fast", 200)
+        assert_same_state(g, o)
+
+
 def test_user_track_from_png_and_svg_on_gpu(product, oracle, tmp_path):
     """f-2 end to end: a generated PNG + SVG centre-line (H V L A Q C S commands) in the reference's template layout ->
     load_track_from_template -> ftgp_create -> sweep and closed loop, GPU vs oracle (a 640 x 480 image: 32 x 24 chunks)."""
