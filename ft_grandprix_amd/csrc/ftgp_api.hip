@@ -1097,8 +1097,12 @@ int ftgp_metrics_allgather_begin(FtgpEnv* e)
         else { HIP_TRY(hipEventRecord(e->ev_gather, e->stream)); e->gather_event = e->ev_gather; }
     } else {
         // the record is produced on the compute stream; everything else happens on the side stream, beside the next launch
-        HIP_TRY(hipEventRecord(e->ev_metrics, e->stream));
-        HIP_TRY(hipStreamWaitEvent(e->side, e->ev_metrics, 0));
+        // (the launch's own stop event -- it rides on the kernel's dispatch packet -- says when the record is there.  An event of its own, recorded behind the
+        // launch, is a barrier packet with a system-scope fence between this launch and the next: measured with a one-rank communicator, the next launch then runs
+        // 20 - 25 us longer -- it finds the L2s flushed -- whatever the exchange itself does: profiles/round5/exchange_overlap_one_rank.log)
+        hipEvent_t ready = (!refresh && e->timed) ? e->ev_stop[slot] : e->ev_metrics;
+        if (ready == e->ev_metrics) HIP_TRY(hipEventRecord(e->ev_metrics, e->stream));
+        HIP_TRY(hipStreamWaitEvent(e->side, ready, 0));
         int r = g_rccl.AllGather(e->d_metrics + so, e->d_gather, FTGP_METRIC_DOUBLES, kNcclFloat64, e->comm, e->side);
         if (r != 0) return fail(FTGP_ERR_COMM, "ncclAllGather: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
         HIP_TRY(hipMemcpyAsync(e->h_gather, e->d_gather, sizeof(double) * FTGP_METRIC_DOUBLES * (size_t)e->world, hipMemcpyDeviceToHost, e->side));
