@@ -230,20 +230,25 @@ __device__ __forceinline__ void sweep_priority(bool second_half)
     if (mine) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
 }
 
-// The march of one wave's rays until ALL of them sit on their terminal cell: hand-written, because what limits this kernel is the
-// number of instructions a SIMD can issue -- of ANY kind: scalar, branch and wait instructions cost about as much as a cheap vector
-// instruction (profiles/round4/salu_cost.log) -- and the compiler's loop spends 13 scalar-side instructions per iteration on mask
-// bookkeeping.  Here a lane leaves the loop by dropping out of exec (v_cmpx on "the cell's entry is a box", i.e. kx != 0), so the
-// body needs no live mask, finished rays hold their cell and crossing time for free (and burn no vector lanes), and the loop
-// closes with one branch on exec: 21 vector (the look-up's six included; rounds 1-4: 23) + 3 scalar-side instructions per iteration, + the
-// near-boundary path.  Priced with tools/issue_calib.sh an iteration costs a SIMD about 85 cycles: two thirds of it selects, compares and conversions.
-// In: exec = the lanes that hold a ray, every one on its start cell; s = 0 (the crossing time into the start cell).
-// Out: mx, my = the terminal cell (cells travelled from the start cell), w = its entry (0 = wall, FTGP_FIELD_OUT = ring), s = crossing time
-// into it, exec as on entry.  The first look-up and jump are peeled (the start cell is (0, 0): no zeroes to set, no byte-select adds).
-// The arithmetic is ftgp_ray_step / ftgp_ray_fix / ftgp_ray_commit of ftgp_march.h, instruction for instruction: a crossing time is
-// fma((float)boundary, iv, -c) -- boundaries counted from the ray's own start cell (round 5; rounds 1-4: convert, subtract the origin's
-// absolute coordinate, multiply).  du, dv come in signed (the body reads their magnitudes through the operand modifier).
-// off0: the byte offset of the start cell's entry (= base).
+// The march of one wave's rays until ALL of them sit on their terminal cell: hand-written, for two reasons that round 5 measured one after the other
+// (DESIGN.md section 6).  (1) Instruction count: scalar, branch and wait instructions cost a SIMD about what a cheap vector instruction costs
+// (profiles/round4/salu_cost.log), and the compiler's loop spends 13 scalar-side instructions per iteration on mask bookkeeping.  Here a lane leaves the
+// loop by dropping out of exec (v_cmpx on "the cell's entry is a box", i.e. kx != 0), so the body needs no live mask, finished rays hold their crossing
+// time for free (and burn no vector lanes), and an iteration is 21 vector (the look-up's six included) + 3 scalar-side instructions, + the near-boundary path.
+// (2) The dependent chain from one look-up to the next, which is what the waves spend most of their life on: the next look-up is issued as soon as the
+// landing estimate's floor is there; the crossing-time select and the near-boundary test (fract, recentre, compare, branch) run in the load's shadow, and a
+// lane that turns out to be within eps of a pixel boundary recomputes its cell (ftgp_ray_fix) and looks up again -- answers return in order, the second
+// overwrites the first.  For the fix path to find the cell the ray came from after the move has been made, the loop runs two iterations per trip with the
+// cell alternating between (mx, my) and (nx, ny).  The first look-up and jump are peeled (the start cell is (0, 0): no zeroes to set, a mask and a shift
+// for the byte-select adds), and the tail of ftgp_ray_place -- g, the origin's offset inside its start cell seen in the direction of travel, and c = g * iv --
+// is worked out in the shadow of that first load.  (-5.4 % and -1.1 % of the headline's cycles: profiles/round5/ab_speculative_lookup.log,
+// ab_setup_latency_experiments.log.)
+// In: exec = the lanes that hold a ray; (pu, pv) = the ray's origin in pixels (on the image, or the ray is parked: base = 0, ax = ay = 0), du, dv signed
+// (the body reads their magnitudes through the operand modifier), ivx, ivy = |1 / du|, |1 / dv| as the specification wants them, base = the byte offset
+// of the start cell's entry, ax, ay = the strides.
+// Out: w = the terminal cell's entry (0 = wall, FTGP_FIELD_OUT = ring), s = the crossing time into it; exec as on entry.
+// The arithmetic is ftgp_ray_place's tail and ftgp_ray_step / ftgp_ray_fix / ftgp_ray_commit of ftgp_march.h, instruction for instruction: a crossing
+// time is fma((float)boundary, iv, -c) -- boundaries counted from the ray's own start cell.
 __device__ __forceinline__ void march_all(float& s, uint32_t& w, float pu, float pv, float ivx, float ivy, float du, float dv,
                                           int base, int ax, int ay, float thr /* 0.5f - eps */, const void* field)
 {
