@@ -3,7 +3,7 @@
 // DISPLACED to a queue (un-started) and marched later in gather groups of 64.  Counts what the schedule costs per car-step: wave-iterations
 // (look-ups a wave issues, each one a dependent memory round trip), groups set up, the longest chain of a workgroup's waves.
 // Field cache of tools/sweep_model.cpp (16 sectors):
-//   g++ -O2 -std=c++17 -I. tools/diag/riders_model.cpp -o /tmp/riders; /tmp/riders /tmp/track.raw /tmp/poses.bin [cars_per_wg] [waves]
+//   g++ -O2 -std=c++17 -I. tools/diag/riders_model.cpp -o /tmp/riders; [LPT=1] [SETUP=2.0] /tmp/riders /tmp/track.raw /tmp/poses.bin [cars_per_wg] [waves]
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -95,7 +95,21 @@ int main(int argc, char** argv)
                 w.clock += it + SETUP;
             };
             const int ntasks = (int)order.size() * cpb;
-            for (int g = 0; g < ntasks; ++g) {
+            // what-if LPT=1: the workgroup's tasks drawn by their TRUE cost (this very pose's look-up counts: the bound for "by the previous step's counts"), longest first
+            std::vector<int> draw(ntasks); for (int g = 0; g < ntasks; ++g) draw[g] = g;
+            if (getenv("LPT")) {
+                auto cost = [&](int g) {
+                    const Task t = order[g / cpb]; const int c = c0 + g % cpb; double sum = 0;
+                    const int lim = t.kind == 1 ? half : R;
+                    if (t.kind == 2) { int m = 0; for (int l = 0; l < 64; ++l) if ((l & 31) < half - t.j0) m = std::max(m, cnt[c][t.j0 + (l & 31) + (l >= 32 ? half : 0)]); return m + SETUP; }
+                    for (int p = 0; p < (t.kind == 1 ? 2 : 1); ++p) { int m = 0; for (int l = 0; l < 64 && t.j0 + l < lim; ++l) m = std::max(m, cnt[c][t.j0 + l + p * half]); sum += m + SETUP; }
+                    return sum;
+                };
+                std::vector<double> cs(ntasks); for (int g = 0; g < ntasks; ++g) cs[g] = cost(g);
+                std::stable_sort(draw.begin(), draw.end(), [&](int a, int b) { return cs[a] > cs[b]; });
+            }
+            for (int gi = 0; gi < ntasks; ++gi) {
+                const int g = draw[gi];
                 Wave& w = *std::min_element(wv.begin(), wv.end(), [](const Wave& a, const Wave& b) { return a.clock < b.clock; });
                 const Task t = order[g / cpb]; const int c = c0 + g % cpb;
                 int fresh[64];
