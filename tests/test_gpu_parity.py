@@ -318,6 +318,22 @@ def test_enlarged_vehicle_box_is_seen(product, oracle):
         assert_same_state(g, o)
 
 
+@pytest.mark.parametrize("n_rays,envs", [(130, 20), (200, 37), (333, 9), (1000, 24), (1084, 70)])
+def test_sweep_task_table_for_other_fans(product, oracle, n_rays, envs):
+    """The sweep's task descriptors (DeviceParams::task_tab) for ray counts other than 1080: a last pair of two rays in one group (130), a partial
+    last pair and window ends inside groups of either half (200), an odd count -- single groups, no pairs -- (333), a half that is no multiple of
+    anything (1000, 1084); batches that leave a ragged last workgroup.  Closed loops of both device drivers -- they read the scan windows the
+    deliveries fill -- against the oracle, bit for bit."""
+    t = load_track("track")
+    for policy in ("nidc", "fast"):
+        g, o = both(product, oracle, t, n_envs=envs, n_rays=n_rays, spawn_mode=1, seed=n_rays)
+        with g, o:
+            g.step(1); o.step(1)
+            np.testing.assert_array_equal(g.lidar(), o.lidar())
+            g.rollout(policy, 400); o.rollout(policy, 400)
+            assert_same_state(g, o)
+
+
 @pytest.mark.parametrize("how", ["puck_outside_the_box", "switch"])
 def test_inter_vehicle_test_with_the_pucks_circle(product, oracle, how, monkeypatch):
     """The inter-vehicle ray test leaves the LiDAR puck's circle out when it lies inside the chassis box (both bundled vehicles: the box's time
