@@ -234,9 +234,10 @@ __device__ __forceinline__ void sweep_priority(bool second_half)
 // (DESIGN.md section 6).  (1) Instruction count: scalar, branch and wait instructions cost a SIMD about what a cheap vector instruction costs
 // (profiles/round4/salu_cost.log), and the compiler's loop spends 13 scalar-side instructions per iteration on mask bookkeeping.  Here a lane leaves the
 // loop by dropping out of exec (v_cmpx on "the cell's entry is a box", i.e. kx != 0), so the body needs no live mask, finished rays hold their crossing
-// time for free (and burn no vector lanes), and an iteration is 21 vector (the look-up's six included) + 3 scalar-side instructions, + the near-boundary path.
+// times for free (and burn no vector lanes), and an iteration is 20 vector (the look-up's six included) + 3 scalar-side instructions, + the near-boundary path;
+// the crossing time into the terminal cell is the smaller of the last jump's two, taken once after the loop.
 // (2) The dependent chain from one look-up to the next, which is what the waves spend most of their life on: the next look-up is issued as soon as the
-// landing estimate's floor is there; the crossing-time select and the near-boundary test (fract, recentre, compare, branch) run in the load's shadow, and a
+// landing estimate's floor is there; the near-boundary test (fract, recentre, compare, branch) runs in the load's shadow, and a
 // lane that turns out to be within eps of a pixel boundary recomputes its cell (ftgp_ray_fix) and looks up again -- answers return in order, the second
 // overwrites the first.  For the fix path to find the cell the ray came from after the move has been made, the loop runs two iterations per trip with the
 // cell alternating between (mx, my) and (nx, ny).  The first look-up and jump are peeled (the start cell is (0, 0): no zeroes to set, a mask and a shift
@@ -276,7 +277,6 @@ __device__ __forceinline__ void march_all(float& s, uint32_t& w, float pu, float
         "v_mad_i32_i24 %[i], " NY ", %[ay], %[base]\n\t"                 /* entry offset = ftgp_ray_offset() */ \
         "v_mad_i32_i24 %[i], " NX ", %[ax], %[i]\n\t" \
         "global_load_ushort %[w], %[i], %[field]\n\t" \
-        "v_cndmask_b32_e64 %[s], %[b], %[a], %[stepx]\n\t"               /* s = sn, the crossing time into the new cell (a lane that ended on the last lookup left exec and keeps its s) */ \
         "v_fract_f32_e32 %[f], %[e]\n\t" \
         "v_add_f32_e32 %[f], -0.5, %[f]\n\t" \
         "v_cmp_gt_f32_e64 vcc, |%[f]|, %[thr]\n\t" \
@@ -290,20 +290,21 @@ __device__ __forceinline__ void march_all(float& s, uint32_t& w, float pu, float
         // ftgp_ray_fix() for the lanes in vcc; cur = the select that yields the transverse coordinate of the cell the ray stands on
 #define FTGP_MARCH_FIX(cur, NX, NY, back) \
         "s_and_saveexec_b64 %[sv], vcc\n\t" \
-        "v_cndmask_b32_e64 %[a], %[cx], %[cy], %[stepx]\n\t"             /* transverse c ... */ \
-        "v_cndmask_b32_e64 %[b], %[ivx], %[ivy], %[stepx]\n\t"           /* ... reciprocal ... */ \
-        cur                                                              /* ... current cell ... */ \
-        "v_cndmask_b32_e64 %[i], %[c], %[d], %[stepx]\n\t" \
-        "v_add_u32_e32 %[i], -1, %[i]\n\t"                               /* ... last cell of the box's span */ \
+        "v_cndmask_b32_e64 %[s], %[cx], %[cy], %[stepx]\n\t"             /* transverse c ... (s, f, i, h: scratch here -- sX, sY stay: the crossing time is their minimum, taken after the loop) */ \
+        "v_cndmask_b32_e64 %[f], %[ivx], %[ivy], %[stepx]\n\t"           /* ... reciprocal */ \
         "v_rndne_f32_e32 %[e], %[e]\n\t"                                 /* the boundary in doubt */ \
-        "v_fma_f32 %[a], %[e], %[b], -%[a]\n\t"                          /* its crossing time, the specification's way */ \
-        "v_cvt_i32_f32_e32 %[b], %[e]\n\t" \
-        "v_cmp_lt_f32_e64 vcc, %[a], %[s]\n\t" \
-        "v_cmp_le_f32_e64 %[sq], %[a], %[s]\n\t" \
+        "v_fma_f32 %[s], %[e], %[f], -%[s]\n\t"                          /* its crossing time, the specification's way */ \
+        "v_cvt_i32_f32_e32 %[f], %[e]\n\t" \
+        "v_min_f32_e32 %[h], %[a], %[b]\n\t"                             /* sn, the crossing time of the jump */ \
+        "v_cmp_lt_f32_e64 vcc, %[s], %[h]\n\t" \
+        "v_cmp_le_f32_e64 %[sq], %[s], %[h]\n\t" \
         "s_and_b64 %[sq], %[sq], %[stepx]\n\t"                           /* crossed: S <= sn after an x-jump, S < sn after a y-jump */ \
         "s_or_b64 vcc, vcc, %[sq]\n\t" \
-        "v_cndmask_b32_e64 %[a], -1, 0, vcc\n\t" \
-        "v_add_u32_e32 %[h], %[b], %[a]\n\t"                             /* the cell beyond the boundary if crossed, else the one before */ \
+        "v_cndmask_b32_e64 %[s], -1, 0, vcc\n\t" \
+        "v_add_u32_e32 %[h], %[f], %[s]\n\t"                             /* the cell beyond the boundary if crossed, else the one before */ \
+        cur                                                              /* the cell the ray stands on (transverse coordinate, into f) ... */ \
+        "v_cndmask_b32_e64 %[i], %[c], %[d], %[stepx]\n\t" \
+        "v_add_u32_e32 %[i], -1, %[i]\n\t"                               /* ... and the last cell of the box's span */ \
         "v_med3_i32 %[h], %[h], %[f], %[i]\n\t"                          /* inside the box's span */ \
         "v_cndmask_b32_e64 " NX ", %[h], %[c], %[stepx]\n\t"             /* the cell and its look-up again (the first look-up's answer arrives first and is overwritten) */ \
         "v_cndmask_b32_e64 " NY ", %[d], %[h], %[stepx]\n\t" \
@@ -327,7 +328,8 @@ __device__ __forceinline__ void march_all(float& s, uint32_t& w, float pu, float
         "v_cndmask_b32_e32 %[gv], %[gv], %[b], vcc\n\t"
         "v_mul_f32_e32 %[cx], %[gu], %[ivx]\n\t"
         "v_mul_f32_e32 %[cy], %[gv], %[ivy]\n\t"
-        "v_mov_b32_e32 %[s], 0\n\t"
+        "v_mov_b32_e32 %[a], 0\n\t"                                      // (a ray that ends on its start cell: its crossing time is min(0, 0))
+        "v_mov_b32_e32 %[b], 0\n\t"
         "s_waitcnt vmcnt(0)\n\t"
         "v_and_b32_e32 %[c], 0xff, %[w]\n\t"                              // xe = kx
         "v_lshrrev_b32_e32 %[d], 8, %[w]\n\t"                             // ye = ky
@@ -359,7 +361,8 @@ __device__ __forceinline__ void march_all(float& s, uint32_t& w, float pu, float
         "L_march_fix2_%=:\n\t"
         FTGP_MARCH_FIX("v_cndmask_b32_e64 %[f], %[nx], %[ny], %[stepx]\n\t", "%[mx]", "%[my]", "L_march_arrive2_%=")
         "L_march_done_%=:\n\t"
-        "s_mov_b64 exec, %[ex0]"
+        "s_mov_b64 exec, %[ex0]\n\t"
+        "v_min_f32_e32 %[s], %[a], %[b]"                                  // the crossing time into the terminal cell: the smaller of the last jump's two (a finished lane's stay as they were)
         : [s] "=&v"(s), [w] "=&v"(w), [mx] "=&v"(mx), [my] "=&v"(my), [nx] "=&v"(nx), [ny] "=&v"(ny),
           [a] "=&v"(a), [b] "=&v"(b), [c] "=&v"(c), [d] "=&v"(d), [e] "=&v"(e), [f] "=&v"(f), [h] "=&v"(h), [i] "=&v"(i),
           [gu] "=&v"(gu), [gv] "=&v"(gv), [cx] "=&v"(cx), [cy] "=&v"(cy),
