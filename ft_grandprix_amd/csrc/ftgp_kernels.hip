@@ -221,7 +221,8 @@ __device__ __forceinline__ float ray_vs_car(const VehLds* V, const LidarFrame* b
 // partners" is only what the dispatcher is observed to do (the hardware promises no order); a wrong guess costs fairness,
 // never correctness.
 #ifndef FTGP_FAIR_SHIFT
-#define FTGP_FAIR_SHIFT 13        // turns of 2^13 ticks = 82 us (measured: 2^12 .. 2^15 are equally good, shorter and longer turns worse)
+#define FTGP_FAIR_SHIFT 14        // turns of 2^14 ticks = 164 us (round 3: 2^12 .. 2^15 equally good; on round 5's kernel 2^14 is 1.2 % ahead of 2^13 in sixteen same-box rows,
+                                  // 2^11, 2^12 and 2^15 behind: profiles/round5/ab_fair_turns.log)
 #endif
 __device__ __forceinline__ void sweep_priority(bool second_half)
 {
